@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the reference itself (runs ONLY in the build
+container, where /root/reference is mounted; never on the GPU box).
+
+Imports mymodel.ViT, mymodel.ViT_mask and utils.masking_generator from the
+reference, drives them on seeded inputs with torch 2.10 CPU fp32, and writes
+small .npz fixtures (plain arrays, no pickles) under tests/golden/:
+
+  vit_<case>.npz   state_dict ("p/<key>"), x, y, logits, loss, grads ("g/<key>"),
+                   per-layer post-softmax probabilities ("probs/<i>") taken with a
+                   forward hook on each Attention.attend module, token features
+                   before pooling ("feat"), config scalars ("cfg/<name>")
+  masks.npz        MaskingGenerator outputs for several (grid, n, seed) triples,
+                   with the shuffled index copy, unk_mask and seq_ord
+
+Usage: PYTHONDONTWRITEBYTECODE=1 python3 tools/gen_golden.py
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+CASES = {
+    # name: (module, ctor kwargs, batch, masked?, train_method)
+    "cifar_dh8": ("ViT", dict(image_size=32, patch_size=4, embed_dim=96, num_classes=10, depth=2,
+                              heads=12, mlp_dim=128), 4, None),
+    "dh64_mean": ("ViT", dict(image_size=64, patch_size=16, embed_dim=128, num_classes=100, depth=2,
+                              heads=2, mlp_dim=256, dim_head=64, pool="mean"), 3, None),
+    "n197_dh64": ("ViT", dict(image_size=224, patch_size=16, embed_dim=64, num_classes=10, depth=1,
+                              heads=2, mlp_dim=128, dim_head=64), 2, None),
+    "identity_out": ("ViT", dict(image_size=32, patch_size=8, embed_dim=32, num_classes=5, depth=1,
+                                 heads=1, mlp_dim=64, dim_head=32), 2, None),
+    "mask_dh8": ("ViT_mask", dict(image_size=32, patch_size=4, embed_dim=96, num_classes=10, depth=2,
+                                  heads=12, mlp_dim=128), 4, "mask"),
+    "mask_none": ("ViT_mask", dict(image_size=32, patch_size=4, embed_dim=96, num_classes=10, depth=2,
+                                   heads=12, mlp_dim=128), 4, "nomask"),
+    "mask_dh64": ("ViT_mask", dict(image_size=64, patch_size=8, embed_dim=64, num_classes=7, depth=1,
+                                   heads=2, mlp_dim=96, dim_head=32), 3, "mask"),
+}
+
+
+def main():
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from mymodel import ViT, ViT_mask
+    from utils.masking_generator import MaskingGenerator
+
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(1)  # deterministic reduction order for the captured numbers
+
+    for name, (modname, kw, B, mode) in CASES.items():
+        torch.manual_seed(1001)
+        mod = ViT if modname == "ViT" else ViT_mask
+        model = mod.VIT(**kw)
+        model.train()
+        # make LayerNorm affine / biases non-trivial so their gradients and use are exercised
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                if k.endswith("norm.weight") or k == "mlp_head.0.weight":
+                    v.add_(0.1 * torch.randn_like(v))
+                if k.endswith("norm.bias") or k == "mlp_head.0.bias":
+                    v.add_(0.1 * torch.randn_like(v))
+        torch.manual_seed(1234)
+        x = torch.randn(B, 3, kw["image_size"], kw["image_size"])
+        y = torch.randint(0, kw["num_classes"], (B,))
+        probs = []
+        hooks = []
+        for layer in model.transformer.layers:
+            hooks.append(layer[0].fn.attend.register_forward_hook(lambda m, i, o: probs.append(o.detach().clone())))
+        feats = []
+        hooks.append(model.transformer.register_forward_hook(lambda m, i, o: feats.append(o.detach().clone())))
+        arrays = {}
+        if modname == "ViT_mask":
+            model.train_method = "mask"
+            if mode == "mask":
+                grid = kw["image_size"] // kw["patch_size"]
+                random.seed(77)
+                np.random.seed(77)
+                flat = MaskingGenerator((grid, grid), (grid * grid) // 2, min_num_patches=4)().flatten()
+                um = np.concatenate([np.zeros((1, 1), np.int32), flat[None, :]], axis=1)
+                unk = torch.from_numpy(um).long()
+                arrays["unk_mask"] = um.astype(np.int64)
+                logits = model(x, unk_mask=unk)
+            else:
+                logits = model(x, unk_mask=None)
+        else:
+            logits = model(x)
+        loss = torch.nn.CrossEntropyLoss()(logits, y)
+        loss.backward()
+        for h in hooks:
+            h.remove()
+        for k, v in model.state_dict().items():
+            arrays["p/" + k] = v.detach().numpy().copy()
+        for k, v in model.named_parameters():
+            arrays["g/" + k] = (v.grad if v.grad is not None else torch.zeros_like(v)).numpy().copy()
+        arrays["x"] = x.numpy()
+        arrays["y"] = y.numpy()
+        arrays["logits"] = logits.detach().numpy()
+        arrays["loss"] = loss.detach().numpy()
+        arrays["feat"] = feats[0].numpy()
+        for i, p in enumerate(probs):
+            arrays[f"probs/{i}"] = p.numpy()
+        for ck, cv in kw.items():
+            if isinstance(cv, str):
+                arrays["cfg/" + ck] = np.array(cv)
+            else:
+                arrays["cfg/" + ck] = np.array(cv, dtype=np.int64)
+        arrays["cfg/masked"] = np.array(int(modname == "ViT_mask"), dtype=np.int64)
+        path = os.path.join(OUT, f"vit_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(name, "loss", float(loss), "bytes", os.path.getsize(path))
+
+    # ---- mask vectors
+    marr = {}
+    cases = [(8, 32), (14, 98), (14, 100), (14, 120), (14, 140), (14, 160), (14, 8), (8, 8), (4, 8)]
+    idx = 0
+    for grid, n in cases:
+        for seed in (0, 1, 1234, 1235, 99991):
+            random.seed(seed)
+            np.random.seed(seed)
+            gen = MaskingGenerator((grid, grid), n, min_num_patches=4)
+            for rep in range(2):  # two consecutive draws from one RNG stream
+                flat = gen().flatten()
+                nz = np.nonzero(flat)[0]
+                sh = nz.copy()
+                np.random.shuffle(sh)
+                um = np.concatenate([np.zeros((1, 1), np.int32), flat[None, :]], axis=1)
+                t = torch.from_numpy(um).long()
+                N = um.shape[1]
+                so = (torch.arange(N).unsqueeze(0) * (1 - t) + t * N).numpy()
+                marr[f"{idx}/meta"] = np.array([grid, n, seed, rep], dtype=np.int64)
+                marr[f"{idx}/flat"] = flat.astype(np.int32)
+                marr[f"{idx}/shuffle"] = sh.astype(np.int64)
+                marr[f"{idx}/unk_mask"] = um.astype(np.int32)
+                marr[f"{idx}/seq_ord"] = so.astype(np.int64)
+                idx += 1
+    marr["count"] = np.array(idx, dtype=np.int64)
+    path = os.path.join(OUT, "masks.npz")
+    np.savez_compressed(path, **marr)
+    print("masks", idx, "bytes", os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    main()
