@@ -1,0 +1,150 @@
+/* vitmi.h -- C ABI of libvitmi_hip.so: the gfx950 (MI355X) kernels behind the ViT encoder
+ * hot path of mrkize/VisionTransformer (mymodel/ViT.py, mymodel/ViT_mask.py).
+ *
+ * The reference is pure Python on PyTorch and has no FFI of its own; each entry point below
+ * replaces the aten kernels that one group of reference lines dispatches, and says which.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = error (see VITMI_ERR_*); the message of the
+ *     last error on the calling thread is vitmi_last_error().  Nothing throws.
+ *   - all pointers are BORROWED device pointers (HBM) unless a comment says "host"; the
+ *     library never frees or keeps them.  Temporary storage is a caller-provided workspace
+ *     whose size comes from the matching *_workspace_bytes() query.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued on it, never synchronised.
+ *   - `dt` is the activation/compute storage type: VITMI_F32 or VITMI_BF16.  Parameters that
+ *     stay in fp32 in every mode (biases, LayerNorm affine, cls token, positional table) are
+ *     typed `const float*`.  Accumulation is always fp32.
+ *   - matrices are row-major; "ld" = elements between consecutive rows.
+ */
+#ifndef VITMI_H
+#define VITMI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITMI_VERSION 100
+
+#define VITMI_F32 0
+#define VITMI_BF16 1
+
+#define VITMI_OK 0
+#define VITMI_ERR_BAD_ARG (-1)
+#define VITMI_ERR_HIP (-2)
+#define VITMI_ERR_UNSUPPORTED (-3)
+
+/* GEMM epilogues (vitmi_gemm `epilogue`) */
+#define VITMI_EPI_NONE 0  /* C = acc [+ bias[n]] [+ residual(m,n)]                                  */
+#define VITMI_EPI_GELU 1  /* pre = acc + bias[n]; aux(m,n) = pre (if aux); C = gelu_erf(pre)        */
+#define VITMI_EPI_DGELU 2 /* C = acc * gelu_erf'(aux(m,n))   (aux = the pre-activation saved above) */
+
+/* kernel families for the launch timers (vitmi_prof_*) */
+#define VITMI_FAM_GEMM 0
+#define VITMI_FAM_ATTN_FWD 1
+#define VITMI_FAM_ATTN_BWD 2
+#define VITMI_FAM_LAYERNORM 3
+#define VITMI_FAM_TOKENS 4
+#define VITMI_FAM_OTHER 5
+#define VITMI_FAM_COUNT 6
+
+int vitmi_version(void);
+const char* vitmi_last_error(void);
+
+/* Launch timers: when enabled, every launch of a kernel family is bracketed by HIP events on
+ * its own stream.  vitmi_prof_read synchronises those events and returns the summed duration
+ * (ms), the summed algorithmic work the launches declared (FLOPs for GEMM/attention, bytes
+ * for the HBM-bound families) and the launch count.  Host pointers.  No reference counterpart
+ * (the reference times whole epochs with time.time(), trainer.py:98,159-161). */
+int vitmi_prof_enable(int on);
+int vitmi_prof_reset(void);
+int vitmi_prof_read(int family, double* total_ms, double* total_work, long long* launches);
+
+/* dst[i] = (dst_dt) src[i].  Replaces Tensor.to(dtype) on parameters/inputs. */
+int vitmi_cast(const void* src, int src_dt, void* dst, int dst_dt, long long n, void* stream);
+
+/* C(m,n) = sum_k A(m,k) * B(n,k) with a fused epilogue; A(m,k) = A[m*sam + k*sak],
+ * B(n,k) = B[n*sbn + k*sbk] (so nn.Linear's y = x W^T is sak = sbk = 1, and the two backward
+ * products are strided views of the same call).  A and B are `dt`; C is `c_dt` (dt or
+ * VITMI_F32); bias is fp32 [N] or NULL; residual is `dt` with row stride ldr or NULL; aux is
+ * `dt` with row stride ldaux or NULL.
+ * Replaces: nn.Linear forward/backward (mymodel/ViT.py:66,69,86,89,148), the residual adds
+ * (:119-120) and nn.GELU (:67). */
+int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long sam, long long sak, const void* B,
+               long long sbn, long long sbk, void* C, long long ldc, int c_dt, int epilogue, const float* bias,
+               const void* residual, long long ldr, void* aux, long long ldaux, void* stream);
+
+/* out[c] = sum_r x[r*ld + c] in fp32 (bias gradients).  workspace: vitmi_colsum_workspace_bytes.
+ * Replaces the bias-gradient reductions autograd runs for nn.Linear / nn.Conv2d. */
+long long vitmi_colsum_workspace_bytes(long long rows, int cols);
+int vitmi_colsum(const void* x, int dt, long long rows, int cols, long long ld, float* out, void* workspace,
+                 void* stream);
+
+/* Patch embedding: Conv2d(C, D, kernel=stride=p) + bias, flatten(2).transpose(1,2)
+ * (mymodel/ViT.py:33,43) as an im2col-free GEMM: the A operand is gathered straight from the
+ * NCHW image.  x is [B,C,H,W] in x_dt; w is [D, C*p*p] in dt; out token j of image b is
+ * written at out + b*out_batch_stride + j*D (dt), so it can land inside a [B,N,D] buffer.  */
+int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, const float* bias, void* out, int dt, int B, int C,
+                          int H, int W, int p, int D, long long out_batch_stride, void* stream);
+/* dW[d, k] = sum_{b,j} dy[b,j,d] * patch(b,j)[k]  (fp32 [D, C*p*p]).  Conv2d weight gradient. */
+int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, long long dy_batch_stride, float* dw, int dt,
+                            int B, int C, int H, int W, int p, int D, void* stream);
+
+/* Token assembly + positional embedding (mymodel/ViT.py:155-159; ViT_mask.py:156-172):
+ *   out[b,0,:]   = cls[:]          + pe[row(0),:]
+ *   out[b,1+j,:] = patch[b,j,:]    + pe[row(1+j),:]
+ * row(i) = seq_ord[i] when seq_ord != NULL (device int64 [N]; ViT_mask.py:162-164), else i;
+ * a negative seq_ord[i] adds nothing to token i (the zero row of ViT_mask.py:166-170);
+ * pe == NULL skips the add (model.PE False).  patch is [B,N-1,D] dt, out is [B,N,D] dt.
+ * pe_rows bounds-checks nothing on device: the caller guarantees 0 <= seq_ord[i] < pe_rows. */
+int vitmi_tokens_assemble_fwd(const void* patch, const float* cls, const float* pe, const long long* seq_ord,
+                              void* out, int dt, int B, int N, int D, void* stream);
+/* Backward of the above for the parameters: dcls[D] = sum_b dx[b,0,:];
+ * dpe[r,:] = sum_b sum_{i: row(i)=r} dx[b,i,:] for r in [0,pe_rows) (rows nobody reads get 0).
+ * Deterministic (fixed summation order).  dpe may be NULL. */
+long long vitmi_tokens_assemble_bwd_workspace_bytes(int N, int D);
+int vitmi_tokens_assemble_bwd(const void* dx, const long long* seq_ord, float* dcls, float* dpe, int pe_rows,
+                              void* workspace, int dt, int B, int N, int D, void* stream);
+
+/* LayerNorm over the last dim (nn.LayerNorm, mymodel/ViT.py:55,147; eps as given).
+ * x rows are ldx apart (lets the head read x[:,0] in place); y is dense [rows,D]. */
+int vitmi_layernorm_fwd(const void* x, long long ldx, const float* gamma, const float* beta, void* y, float* mean,
+                        float* rstd, int dt, long long rows, int D, float eps, void* stream);
+/* dx = LN'(dy) [+ dres]; dgamma/dbeta fp32 [D].  dres (dt, dense [rows,D]) may be NULL. */
+long long vitmi_layernorm_bwd_workspace_bytes(long long rows, int D);
+int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx, const float* gamma, const float* mean,
+                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace,
+                        int dt, long long rows, int D, void* stream);
+
+/* Multi-head self-attention core (mymodel/ViT.py:96-103): qkv is [B,N,3*H*DH] laid out as
+ * the to_qkv output (q | k | v, each head-major), out is [B,N,H*DH] ('b h n d -> b n (h d)').
+ * scores = (q k^T) * DH^-0.5 (scale after the matmul), softmax over keys, out = probs v.
+ * lse [B,H,N] fp32 receives log-sum-exp of the scaled scores (kept for backward).
+ * probs ([B,H,N,N] dt) may be NULL; when given it receives the post-softmax probabilities the
+ * reference hands to forward hooks on Attention.attend (ViT.py:100) / attn_drop. */
+int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, int B, int N, int H, int DH,
+                   void* stream);
+/* dqkv from dout, recomputing the probabilities from qkv and lse.  dprobs ([B,H,N,N] dt,
+ * gradient flowing into the exported probabilities) may be NULL. */
+long long vitmi_attn_bwd_workspace_bytes(int dt, int B, int N, int H, int DH);
+int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const void* dprobs,
+                   void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, void* stream);
+
+/* mean over tokens: out[b,:] = mean_i x[b,i,:]  (pool == 'mean', mymodel/ViT.py:164) and its
+ * backward dx[b,i,:] = dout[b,:] / N. */
+int vitmi_meanpool_fwd(const void* x, void* out, int dt, int B, int N, int D, void* stream);
+int vitmi_meanpool_bwd(const void* dout, void* dx, int dt, int B, int N, int D, void* stream);
+
+/* y = a + b elementwise (dt); gradient accumulation on the residual stream. */
+int vitmi_add(const void* a, const void* b, void* y, int dt, long long n, void* stream);
+
+/* Fused Adam step over one flat fp32 parameter tensor (torch.optim.Adam semantics with
+ * weight_decay added to the gradient, trainer.py:204-205), optionally refreshing a bf16 copy
+ * of the parameter in the same pass.  step is the 1-based step count. */
+int vitmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                    long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                    float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITMI_H */

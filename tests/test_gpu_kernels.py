@@ -1,0 +1,247 @@
+"""GPU parity tests, kernel by kernel: each C-ABI entry point against the CPU oracle (or the
+plain fp32 torch expression of the same op) on seeded inputs.  fp32 kernels: 1e-4 relative;
+bf16 kernels: 2e-2 relative (relative = max|a-b| / max|b|)."""
+import math
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import vit_oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from visiontransformer_amd import ops as o
+    return o
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def q(t, dtype):
+    """value the kernel really sees: rounded to the compute dtype, back in fp32 on the CPU"""
+    return t.to(dtype).float()
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+SHAPES = [(128, 128, 64), (256, 384, 192), (197, 288, 192), (65, 96, 96), (50, 10, 48), (1, 100, 768),
+          (300, 200, 72), (130, 130, 130), (64, 512, 1000)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_linear_forward_backward_products(ops, dtype, M, N, K):
+    x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(M, N, seed=3)
+    bias = rnd(N, seed=4)
+    xd, wd, dyd = x.to(DEV, dtype), w.to(DEV, dtype), dy.to(DEV, dtype)
+    y, _ = ops.linear_fwd(xd, wd, bias.to(DEV))
+    assert rel_err(y, q(x, dtype) @ q(w, dtype).t() + bias) < TOL[dtype]
+    dx = ops.linear_bwd_x(dyd, wd)
+    assert rel_err(dx, q(dy, dtype) @ q(w, dtype)) < TOL[dtype]
+    dw = ops.linear_bwd_w(dyd, xd)
+    assert dw.dtype == torch.float32
+    assert rel_err(dw, q(dy, dtype).t() @ q(x, dtype)) < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 200, 136, 96
+    x, w, b, r = rnd(M, K, seed=5), rnd(N, K, seed=6, scale=K ** -0.5), rnd(N, seed=7), rnd(M, N, seed=8)
+    xd, wd, bd, rd = x.to(DEV, dtype), w.to(DEV, dtype), b.to(DEV), r.to(DEV, dtype)
+    pre = q(x, dtype) @ q(w, dtype).t() + b
+    y, _ = ops.linear_fwd(xd, wd, bd, res=rd)
+    assert rel_err(y, pre + q(r, dtype)) < TOL[dtype]
+    h, u = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_GELU, want_aux=True)
+    assert rel_err(u, pre) < TOL[dtype]
+    assert rel_err(h, vit_oracle.gelu_erf(pre)) < TOL[dtype]
+    # dGELU epilogue: (dy @ W2) * gelu'(u)
+    w2, dy = rnd(K, N, seed=9, scale=N ** -0.5), rnd(M, K, seed=10)
+    du = ops.linear_bwd_x(dy.to(DEV, dtype), w2.to(DEV, dtype), epi=ops.EPI_DGELU, aux=u)
+    uu = u.float().cpu().requires_grad_(True)
+    vit_oracle.gelu_erf(uu).backward(q(dy, dtype) @ q(w2, dtype))
+    assert rel_err(du, uu.grad) < TOL[dtype]
+    # fp32 output from bf16 operands with bias (the classifier head)
+    y32, _ = ops.linear_fwd(xd, wd, bd, out_dtype=torch.float32)
+    assert y32.dtype == torch.float32 and rel_err(y32, pre) < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+def test_gemm_strided_views_and_unaligned(ops):
+    # operands that are column slices of wider buffers (row stride > K) and odd sizes force the scalar loaders
+    big = rnd(77, 300, seed=11).to(DEV, torch.bfloat16)
+    x = big[:, 3:3 + 50]                      # unaligned start, K = 50
+    w = rnd(33, 50, seed=12).to(DEV, torch.bfloat16)
+    y, _ = ops.linear_fwd(x, w)
+    assert rel_err(y, x.float().cpu() @ w.float().cpu().t()) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm / reductions
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,D", [(4 * 65, 192), (197, 768), (7, 96), (3, 50), (1030, 384)])
+def test_layernorm(ops, dtype, rows, D):
+    x, g, b, dy, res = rnd(rows, D, seed=1), 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3), rnd(rows, D, seed=4), \
+        rnd(rows, D, seed=5)
+    xd = x.to(DEV, dtype)
+    y, mean, rstd = ops.layernorm_fwd(xd, g.to(DEV), b.to(DEV), 1e-5)
+    xr = q(x, dtype).requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = vit_oracle.layer_norm(xr, gr, br)
+    assert rel_err(y, yr) < TOL[dtype]
+    assert rel_err(mean, xr.mean(-1)) < 1e-5 + (0 if dtype == torch.float32 else 1e-3)
+    yr.backward(q(dy, dtype))
+    dx, dg, db = ops.layernorm_bwd(dy.to(DEV, dtype), xd, g.to(DEV), mean, rstd, dres=res.to(DEV, dtype))
+    assert rel_err(dx, xr.grad + q(res, dtype)) < TOL[dtype]
+    assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+
+
+def test_layernorm_strided_rows(ops):
+    # the head normalises x[:, 0] in place: rows N*D apart
+    x = rnd(6, 5, 64, seed=6).to(DEV)
+    g, b = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    y, _, _ = ops.layernorm_fwd(x[:, 0], g, b, 1e-5)
+    assert rel_err(y, vit_oracle.layer_norm(x[:, 0].cpu(), g.cpu(), b.cpu())) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(1000, 768), (13, 10), (50432, 96), (257, 100)])
+def test_colsum(ops, dtype, rows, cols):
+    x = rnd(rows, cols, seed=7).to(DEV, dtype)
+    assert rel_err(ops.colsum(x), x.double().cpu().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ tokens + PE
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("masked", [False, True])
+def test_tokens_assemble(ops, dtype, masked):
+    B, N, D = 5, 17, 96
+    patch, cls = rnd(B, N - 1, D, seed=1), rnd(1, 1, D, seed=2)
+    pe = rnd(N + 1 if masked else N, D, seed=3)
+    seq = None
+    if masked:
+        m = torch.zeros(1, N, dtype=torch.long)
+        m[0, [2, 3, 9, 16]] = 1
+        seq = vit_oracle.seq_ord_from_mask(m, N).squeeze(0)
+    pr, cr, per = q(patch, dtype).requires_grad_(True), cls.clone().requires_grad_(True), pe.clone().requires_grad_(True)
+    ref = torch.cat([cr.expand(B, -1, -1), pr], 1) + (per[seq] if masked else per[:N])
+    pd = patch.to(DEV, dtype).requires_grad_(True)
+    cd, ped = cls.to(DEV).requires_grad_(True), pe.to(DEV).requires_grad_(True)
+    out = ops.TokensFn.apply(pd, cd, ped, seq.to(DEV) if masked else None)
+    assert rel_err(out, ref) < TOL[dtype]
+    dy = rnd(B, N, D, seed=4)
+    ref.backward(q(dy, dtype))
+    out.backward(dy.to(DEV, dtype))
+    assert rel_err(pd.grad, pr.grad) < TOL[dtype]
+    assert rel_err(cd.grad, cr.grad) < 1e-5 and rel_err(ped.grad, per.grad) < 1e-5
+    if masked:
+        assert ped.grad[[2, 3, 9, 16]].abs().max() == 0 and ped.grad[N].abs().max() > 0
+
+
+def test_tokens_gradient_is_deterministic(ops):
+    B, N, D = 64, 65, 192
+    dx = rnd(B, N, D, seed=5).to(DEV, torch.bfloat16)
+    seq = torch.arange(N)
+    seq[1::2] = N
+    outs = []
+    for _ in range(2):
+        p = torch.zeros(B, N - 1, D, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+        c = torch.zeros(1, 1, D, device=DEV, requires_grad=True)
+        pe = torch.zeros(N + 1, D, device=DEV, requires_grad=True)
+        ops.TokensFn.apply(p, c, pe, seq.to(DEV)).backward(dx)
+        outs.append(pe.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------ patch embedding
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("img,p,C,D,B", [(32, 4, 3, 96, 3), (64, 16, 3, 128, 2), (224, 16, 3, 64, 1), (24, 8, 1, 40, 2)])
+def test_patch_embed(ops, dtype, img, p, C, D, B):
+    x, w, b = rnd(B, C, img, img, seed=1), rnd(D, C, p, p, seed=2, scale=(C * p * p) ** -0.5), rnd(D, seed=3)
+    xr = (q(x, dtype) if dtype == torch.bfloat16 else x).requires_grad_(True)
+    wr, br = q(w, dtype).requires_grad_(True), b.clone().requires_grad_(True)
+    ref = vit_oracle.patch_embed(xr, wr, br)
+    xd = x.to(DEV).requires_grad_(True)
+    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    out = ops.PatchEmbedFn.apply(xd, wd, bd, dtype)
+    assert out.shape == ref.shape and rel_err(out, ref) < TOL[dtype]
+    dy = rnd(*ref.shape, seed=4)
+    ref.backward(q(dy, dtype))
+    out.backward(dy.to(DEV, dtype))
+    assert rel_err(wd.grad, wr.grad) < (1e-4 if dtype == torch.float32 else 5e-3)
+    assert rel_err(bd.grad, br.grad) < 1e-4
+    assert rel_err(xd.grad, xr.grad) < TOL[dtype]
+
+
+# ------------------------------------------------------------------------------------------ attention core
+def attn_ref(qkv, H, DH):
+    B, N, _ = qkv.shape
+    I = H * DH
+    q_, k_, v_ = (t.reshape(B, N, H, DH).permute(0, 2, 1, 3) for t in qkv.split(I, dim=-1))
+    dots = (q_ @ k_.transpose(-1, -2)) * DH ** -0.5
+    probs = torch.softmax(dots, -1)
+    return (probs @ v_).permute(0, 2, 1, 3).reshape(B, N, I), probs, torch.logsumexp(dots, -1)
+
+
+ATTN_CASES = [(2, 65, 12, 8), (2, 197, 3, 64), (1, 17, 2, 32), (3, 50, 4, 16), (1, 256, 2, 64), (2, 1, 2, 8),
+              (1, 100, 1, 64), (2, 33, 2, 64)]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,N,H,DH", ATTN_CASES)
+def test_attention_forward_backward(ops, dtype, B, N, H, DH):
+    qkv = rnd(B, N, 3 * H * DH, seed=1, scale=1.5)
+    qr = q(qkv, dtype).requires_grad_(True)
+    o_ref, p_ref, lse_ref = attn_ref(qr, H, DH)
+    qd = qkv.to(DEV, dtype)
+    o, lse, probs = ops.attn_fwd(qd, B, N, H, DH, True)
+    assert rel_err(o, o_ref) < TOL[dtype]
+    assert rel_err(probs, p_ref) < TOL[dtype]
+    assert rel_err(lse, lse_ref) < 1e-4
+    o2, _, none = ops.attn_fwd(qd, B, N, H, DH, False)
+    assert none is None and torch.equal(o, o2)            # export does not change the numerics
+    do = rnd(B, N, H * DH, seed=2)
+    o_ref.backward(q(do, dtype))
+    dqkv = ops.attn_bwd(qd, o, do.to(DEV, dtype), lse, B, N, H, DH)
+    assert rel_err(dqkv, qr.grad) < TOL[dtype]
+
+
+def test_attention_spiky_scores(ops):
+    # one key dominates a row by a wide margin, another row is all-equal: exercises max-subtraction
+    B, N, H, DH = 1, 70, 1, 64
+    qkv = rnd(B, N, 3 * DH, seed=3, scale=0.1)
+    qkv[0, 5, :DH] = 6.0
+    qkv[0, 40, DH:2 * DH] = 6.0
+    qkv[0, 7, :DH] = 0.0
+    for dtype in (torch.float32, torch.bfloat16):
+        o_ref, p_ref, _ = attn_ref(q(qkv, dtype), H, DH)
+        o, lse, probs = ops.attn_fwd(qkv.to(DEV, dtype), B, N, H, DH, True)
+        assert torch.isfinite(o.float()).all() and rel_err(o, o_ref) < TOL[dtype]
+        assert rel_err(probs, p_ref) < TOL[dtype]
+        assert abs(probs[0, 0, 7].float().sum().item() - 1.0) < 1e-2
+
+
+def test_attention_rejects_long_sequences(ops):
+    from visiontransformer_amd._lib import VitmiError
+    with pytest.raises(VitmiError, match="256"):
+        ops.attn_fwd(torch.zeros(1, 300, 3 * 64, device=DEV, dtype=torch.bfloat16), 1, 300, 1, 64, False)
+
+
+# ------------------------------------------------------------------------------------------ misc
+def test_cast_add_meanpool(ops):
+    x = rnd(1001, seed=1).to(DEV)
+    xb = ops.cast(x, torch.bfloat16)
+    assert torch.equal(xb.cpu(), x.cpu().to(torch.bfloat16))       # RNE, bit-exact vs torch's CPU cast
+    assert torch.equal(ops.cast(xb, torch.float32).cpu(), xb.cpu().float())
+    a, b = rnd(777, seed=2).to(DEV), rnd(777, seed=3).to(DEV)
+    assert torch.equal(ops.add(a, b).cpu(), a.cpu() + b.cpu())
+    t = rnd(3, 17, 40, seed=4).to(DEV).requires_grad_(True)
+    m = ops.MeanPoolFn.apply(t)
+    assert rel_err(m, t.detach().cpu().mean(1)) < 1e-6
+    m.sum().backward()
+    assert rel_err(t.grad, torch.full((3, 17, 40), 1 / 17)) < 1e-6

@@ -1,0 +1,165 @@
+"""GPU parity tests, whole model: the nn.Module drop-ins against (a) the fixtures captured from
+the reference modules and (b) the CPU oracle at larger sizes.  Bars: fp32 logits/grads 1e-4
+relative, bf16 2e-2 relative (relative = max|a-b| / max|b| per tensor)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, VIT_CASES, rel_err
+from oracle import masking_oracle, vit_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+
+
+def build(g, dtype):
+    from visiontransformer_amd import ViT, ViT_mask
+    mod = ViT_mask if g.masked else ViT
+    m = mod.VIT(**g.ctor_kwargs())
+    m.load_state_dict(g.params, strict=True)
+    m = m.to(DEV).set_compute_dtype(dtype)
+    if g.masked:
+        m.train_method = "mask"
+    m.train()
+    return m
+
+
+def run(m, g):
+    if g.masked:
+        return m(g.x.to(DEV), unk_mask=g.unk_mask.to(DEV) if g.unk_mask is not None else None)
+    return m(g.x.to(DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", VIT_CASES)
+def test_logits_loss_grads_against_reference_fixture(case, dtype):
+    g = Golden(case)
+    m = build(g, dtype)
+    logits = run(m, g)
+    assert logits.dtype == torch.float32 and logits.shape == g.logits.shape
+    assert rel_err(logits, g.logits) < TOL[dtype]
+    loss = torch.nn.CrossEntropyLoss()(logits, g.y.to(DEV))
+    assert abs(loss.item() - float(g.loss)) < TOL[dtype] * max(1.0, abs(float(g.loss)))
+    loss.backward()
+    got = dict(m.named_parameters())
+    assert set(got) == set(g.grads)
+    worst = max((rel_err(got[k].grad, ref), k) for k, ref in g.grads.items() if ref.abs().max() > 0)
+    assert worst[0] < TOL[dtype], worst
+    for k, ref in g.grads.items():
+        if ref.abs().max() == 0:
+            assert got[k].grad is None or got[k].grad.abs().max() == 0, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", ["cifar_dh8", "n197_dh64", "mask_dh8"])
+def test_attention_map_export_and_features(case, dtype):
+    """forward hooks on `attend` (the reference's softmax module) and on `attn_drop` (the name
+    vit_rollout.py looks for) both observe the [B,H,N,N] probabilities of every layer."""
+    g = Golden(case)
+    m = build(g, dtype).eval()
+    seen_a, seen_d = [], []
+    hooks = []
+    for name, mod in m.named_modules():
+        if name.endswith("attend"):
+            hooks.append(mod.register_forward_hook(lambda mm, i, o: seen_a.append(o)))
+        if "attn_drop" in name:
+            hooks.append(mod.register_forward_hook(lambda mm, i, o: seen_d.append(o)))
+    with torch.no_grad():
+        feat = m.forward_features(g.x.to(DEV), g.unk_mask.to(DEV) if g.unk_mask is not None else None)
+    assert rel_err(feat, g.feat) < TOL[dtype]
+    assert len(seen_a) == len(seen_d) == len(g.probs)
+    for i, p in enumerate(seen_a):
+        assert p.shape == g.probs[i].shape
+        assert rel_err(p, g.probs[i]) < TOL[dtype]
+        assert (p.float().sum(-1) - 1).abs().max() < (1e-5 if dtype == torch.float32 else 1e-2)
+    for h in hooks:
+        h.remove()
+    # without hooks and with fused_attn left True nothing is exported
+    seen_a.clear()
+    for b in m.blocks:
+        b.attn.last_probs = None
+    with torch.no_grad():
+        m.forward_features(g.x.to(DEV), None)
+    assert not seen_a and all(b.attn.last_probs is None for b in m.blocks)
+    # the trainer's switch (fused_attn = False) turns export on without hooks
+    for b in m.blocks:
+        b.attn.fused_attn = False
+        b.attn.last_probs = None
+    with torch.no_grad():
+        m.forward_features(g.x.to(DEV), None)
+    assert all(b.attn.last_probs is not None for b in m.blocks)
+
+
+def test_zero_train_method_and_pe_switch():
+    g = Golden("mask_dh8")
+    m = build(g, torch.float32)
+    m.train_method = "zero"
+    um = g.unk_mask
+    out = m(g.x.to(DEV), unk_mask=um.to(DEV))
+    ref = vit_oracle.forward(g.params, g.x, g.cfg["heads"], unk_mask=um, train_method="zero")
+    assert rel_err(out, ref) < 1e-4
+    m.PE = False                                     # MIA.py:238-240 toggles this attribute
+    out = m(g.x.to(DEV), unk_mask=um.to(DEV))
+    ref = vit_oracle.forward(g.params, g.x, g.cfg["heads"], unk_mask=um, use_pe=False)
+    assert rel_err(out, ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cifar_geometry_batch64_against_oracle(dtype):
+    """BASELINE config 1/3 geometry (32x32, patch 4, D192, 12 heads of 8, mlp 512), masked variant,
+    mask drawn by the product sampler under the seed the oracle sampler uses."""
+    from visiontransformer_amd import ViT_mask
+    from visiontransformer_amd.masking_generator import MaskingGenerator
+    kw = dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=3, heads=12, mlp_dim=512)
+    params = vit_oracle.init_params(masked=True, seed=5, **kw)
+    random.seed(1234), np.random.seed(1234)
+    flat, _, _ = MaskingGenerator((8, 8), 32, min_num_patches=4).masked_indexes()
+    random.seed(1234), np.random.seed(1234)
+    flat_o, _, _ = masking_oracle.masked_indexes(8, 8, 32, 4)
+    assert np.array_equal(flat, flat_o)
+    um = torch.from_numpy(MaskingGenerator.unk_mask_from_flat(flat)).long()
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(64, 3, 32, 32, generator=gen)
+    y = torch.randint(0, 10, (64,), generator=gen)
+    logits_ref, loss_ref, grads_ref = vit_oracle.loss_and_grads(params, x, y, 12, unk_mask=um)
+    m = ViT_mask.VIT(**kw)
+    m.load_state_dict(params)
+    m = m.to(DEV).set_compute_dtype(dtype)
+    m.train_method = "mask"
+    logits = m(x.to(DEV), unk_mask=um.to(DEV))
+    assert rel_err(logits, logits_ref) < TOL[dtype]
+    torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
+    worst = max((rel_err(p.grad, grads_ref[k]), k) for k, p in m.named_parameters())
+    assert worst[0] < TOL[dtype], worst
+
+
+def test_vit_b16_shape_properties():
+    """ViT-B/16 224px geometry at a batch the oracle cannot reach in seconds: size-independent
+    properties -- determinism, rows of the exported maps sum to one, batch independence."""
+    from visiontransformer_amd import ViT
+    torch.manual_seed(1001)
+    m = ViT.VIT(224, 16, 768, 100, 2, 12, 3072, dim_head=64).to(DEV)
+    x = torch.randn(16, 3, 224, 224, device=DEV)
+    for b in m.blocks:
+        b.attn.fused_attn = False
+    with torch.no_grad():
+        a = m(x)
+        probs = [b.attn.last_probs for b in m.blocks]
+        bb = m(x)
+        half = m(x[:8])
+    assert torch.equal(a, bb)                                  # bitwise reproducible
+    assert torch.equal(a[:8], half)                            # images do not interact
+    for p in probs:
+        assert p.shape == (16, 12, 197, 197)
+        assert (p.float().sum(-1) - 1).abs().max() < 1e-2
+        assert p.float().min() >= 0
+    out = m(x)
+    out.square().mean().backward()
+    g1 = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    m(x).square().mean().backward()
+    assert all(torch.equal(u, v.grad) for u, v in zip(g1, m.parameters()))   # deterministic backward
+    assert all(torch.isfinite(gg).all() for gg in g1)

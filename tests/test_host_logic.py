@@ -1,0 +1,129 @@
+"""CPU-side checks: mask sampler bit-exactness, module/state_dict layout against the reference
+fixtures, C-ABI export list, loud failure on CPU tensors."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT, Golden, VIT_CASES
+
+import visiontransformer_amd as vta
+from visiontransformer_amd import ViT, ViT_mask, _lib
+from visiontransformer_amd.masking_generator import MaskingGenerator, seq_ord_from_unk_mask
+
+
+def build_model(g):
+    mod = ViT_mask if g.masked else ViT
+    return mod.VIT(**g.ctor_kwargs())
+
+
+def test_mask_sampler_bit_exact_against_reference_vectors():
+    z = np.load(os.path.join(GOLDEN, "masks.npz"), allow_pickle=False)
+    count = int(z["count"])
+    i = 0
+    while i < count:
+        grid, n, seed, rep = (int(v) for v in z[f"{i}/meta"])
+        random.seed(seed)
+        np.random.seed(seed)
+        gen = MaskingGenerator((grid, grid), n, min_num_patches=4)
+        for r in range(2):
+            flat, nz, sh = gen.masked_indexes()
+            assert flat.dtype == np.int32
+            np.testing.assert_array_equal(flat, z[f"{i + r}/flat"])
+            np.testing.assert_array_equal(sh, z[f"{i + r}/shuffle"])
+            um = MaskingGenerator.unk_mask_from_flat(flat)
+            assert um.dtype == np.int32 and um.shape == (1, grid * grid + 1)
+            np.testing.assert_array_equal(um, z[f"{i + r}/unk_mask"])
+            np.testing.assert_array_equal(seq_ord_from_unk_mask(um), z[f"{i + r}/seq_ord"])
+        i += 2
+
+
+def test_mask_sampler_edge_cases():
+    random.seed(3)
+    assert MaskingGenerator(8, 0)().sum() == 0                     # nothing requested
+    m = MaskingGenerator((8, 8), 64, min_num_patches=4)()          # everything requested
+    assert m.shape == (8, 8) and m.dtype == np.int32 and 0 < m.sum() <= 64
+    g = MaskingGenerator(14, 98)
+    assert g.min_num_patches == 8 and g.max_num_patches == 98     # reference defaults
+    assert "Generator(14, 14 -> [8 ~ 98], max = 98" in repr(g)
+
+
+@pytest.mark.parametrize("case", VIT_CASES)
+def test_state_dict_layout_matches_reference(case):
+    g = Golden(case)
+    model = build_model(g)
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(g.params.keys())
+    for k, v in g.params.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        assert sd[k].dtype == torch.float32
+    model.load_state_dict(g.params, strict=True)                   # the reference's tensors load strictly
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, g.params[k])
+
+
+def test_constructor_contract():
+    with pytest.raises(AssertionError):
+        ViT.VIT(30, 4, 32, 10, 1, 2, 64)                           # image not divisible by patch
+    with pytest.raises(AssertionError):
+        ViT.VIT(32, 4, 32, 10, 1, 2, 64, pool="max")
+    m = ViT.VIT(32, 4, 32, 10, 1, 2, 64, PE=False)
+    assert m.PE is True                                            # ctor argument ignored, as in the reference
+    mm = ViT_mask.VIT(32, 4, 32, 10, 1, 2, 64)
+    assert mm.train_method == "zero" and mm.unk_embed_index == 65
+    assert tuple(mm.pos_embedding.shape) == (1, 66, 32) and tuple(m.pos_embedding.shape) == (65, 32)
+    ident = ViT.VIT(32, 8, 32, 5, 1, 1, 64, dim_head=32)
+    assert isinstance(ident.transformer.layers[0][0].fn.to_out, torch.nn.Identity)
+    # timm-style aliases used by trainer.py / vit_rollout.py
+    assert len(m.blocks) == 1 and m.blocks[0].attn.num_heads == 2 and m.embed_dim == 32
+    for blk in m.blocks:
+        blk.attn.fused_attn = False
+    assert m.transformer.layers[0][0].fn.fused_attn is False
+    assert any("attn_drop" in n for n, _ in m.named_modules())
+
+
+def test_creat_vit_reads_config_patch():
+    class NS:
+        pass
+    cfg = NS()
+    cfg.patch = NS()
+    for k, v in dict(image_size=32, patch_size=4, num_classes=10, embed_dim=48, depth=1, heads=3, mlp_dim=64,
+                     dropout=0, emb_dropout=0, channels=3).items():
+        setattr(cfg.patch, k, v)
+    m = ViT.creat_VIT(cfg)
+    assert m.transformer.layers[0][0].fn.to_qkv.weight.shape == (3 * 3 * 8, 48)   # dim_head stays 8
+    m2 = ViT_mask.creat_VIT(cfg)
+    assert tuple(m2.pos_embedding.shape) == (1, 66, 48)
+
+
+def test_cpu_tensors_fail_loudly():
+    m = ViT.VIT(32, 4, 32, 10, 1, 2, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.randn(1, 3, 32, 32))
+    with pytest.raises(AssertionError, match="doesn't match model"):
+        m(torch.randn(1, 3, 16, 16))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "vitmi.h")).read()
+    declared = set(re.findall(r"\b(vitmi_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/vitmi.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    assert lib.vitmi_version() == 100
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    # argument validation happens before any HIP call
+    rc = _lib.lib.vitmi_gemm(1, 0, 4, 4, None, 1, 1, None, 1, 1, None, 4, 1, 0, None, None, 0, None, 0, None)
+    assert rc == -1 and b"null operand" in _lib.lib.vitmi_last_error()
+    rc = _lib.lib.vitmi_attn_fwd(1, 1, 1, None, 1, 1, 300, 1, 64, None)
+    assert rc == -3 and b"256" in _lib.lib.vitmi_last_error()
+    with pytest.raises(_lib.VitmiError):
+        _lib.check(rc, "attn")

@@ -1,0 +1,78 @@
+"""ctypes binding of libvitmi_hip.so (the C ABI declared in include/vitmi.h).
+
+The library is the only compute path of this package: if it is missing or fails to load the
+import of this module raises, there is no fallback.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvitmi_hip.so")
+
+F32, BF16 = 0, 1
+EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+FAM_GEMM, FAM_ATTN_FWD, FAM_ATTN_BWD, FAM_LAYERNORM, FAM_TOKENS, FAM_OTHER = range(6)
+
+P, I, L, F = c_void_p, c_int, c_longlong, c_float
+
+# name -> (restype, argtypes); mirrors include/vitmi.h one to one
+SIGNATURES = {
+    "vitmi_version": (I, []),
+    "vitmi_last_error": (c_char_p, []),
+    "vitmi_prof_enable": (I, [I]),
+    "vitmi_prof_reset": (I, []),
+    "vitmi_prof_read": (I, [I, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(c_longlong)]),
+    "vitmi_cast": (I, [P, I, P, I, L, P]),
+    "vitmi_gemm": (I, [I, I, I, I, P, L, L, P, L, L, P, L, I, I, P, P, L, P, L, P]),
+    "vitmi_colsum_workspace_bytes": (L, [L, I]),
+    "vitmi_colsum": (I, [P, I, L, I, L, P, P, P]),
+    "vitmi_patch_embed_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, L, P]),
+    "vitmi_patch_embed_bwd_w": (I, [P, I, P, L, P, I, I, I, I, I, I, I, P]),
+    "vitmi_tokens_assemble_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "vitmi_tokens_assemble_bwd_workspace_bytes": (L, [I, I]),
+    "vitmi_tokens_assemble_bwd": (I, [P, P, P, P, I, P, I, I, I, I, P]),
+    "vitmi_layernorm_fwd": (I, [P, L, P, P, P, P, P, I, L, I, F, P]),
+    "vitmi_layernorm_bwd_workspace_bytes": (L, [L, I]),
+    "vitmi_layernorm_bwd": (I, [P, P, L, P, P, P, P, P, P, P, P, I, L, I, P]),
+    "vitmi_attn_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vitmi_attn_bwd_workspace_bytes": (L, [I, I, I, I, I]),
+    "vitmi_attn_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "vitmi_meanpool_fwd": (I, [P, P, I, I, I, I, P]),
+    "vitmi_meanpool_bwd": (I, [P, P, I, I, I, I, P]),
+    "vitmi_add": (I, [P, P, P, I, L, P]),
+    "vitmi_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, F, I, F, P]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m visiontransformer_amd.build` "
+            "(hipcc --offload-arch=gfx950).  This package has no other compute path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header and library disagree
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class VitmiError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    """Turn a negative C-ABI return code into a Python exception carrying the library's message."""
+    if rc != 0:
+        msg = lib.vitmi_last_error()
+        raise VitmiError(f"{what or 'vitmi'} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def prof_read(family):
+    ms, work, n = c_double(), c_double(), c_longlong()
+    check(lib.vitmi_prof_read(family, ctypes.byref(ms), ctypes.byref(work), ctypes.byref(n)), "vitmi_prof_read")
+    return ms.value, work.value, n.value

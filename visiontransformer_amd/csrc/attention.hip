@@ -1,0 +1,747 @@
+// Multi-head self-attention core for ViT sequence lengths (N <= 256 tokens: all keys of one
+// head fit in LDS, so the softmax is a single exact pass over the whole row -- the online
+// rescale of a streaming flash kernel never triggers at these lengths).
+//
+// bf16 kernels (v_mfma_f32_16x16x32_bf16), one workgroup per (image, head):
+//   forward : K and V^T of the head are staged once in LDS.  A wave owns 16 query rows and
+//             computes S^T = K Q^T with the QUERY on the MFMA lane, so the softmax reduction is
+//             over that lane's registers plus two cross-lane steps, and the probability
+//             registers are directly the B operand of O^T = V^T P^T.  Key rows are fed to the
+//             first product in a permuted order chosen so that those registers come out in
+//             natural key order.  The same normalised bf16 probabilities feed P V and the
+//             optional export to HBM.
+//   backward: two kernels that both recompute P from (Q, K, lse):
+//             dK/dV -- a wave owns 16 keys, sweeps all queries, accumulates dK^T, dV^T in
+//                      registers (S, dP computed with the KEY on the lane -> P, dS are B operands);
+//             dQ    -- a wave owns 16 queries, sweeps all keys, accumulates dQ^T
+//                      (S^T, dP^T with the QUERY on the lane -> dS^T is the B operand).
+//             No atomics, no cross-wave reduction: results are bitwise reproducible.
+// fp32 kernels: one wave per query (or key) row, plain FMA; the parity path.
+#include "common.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+    return z;
+}
+
+// permuted row -> sequence index inside a 32-wide chunk: the MFMA output register r of lane
+// group g (rows 4g+r) of sub-tile u then holds sequence index 32c + 8g + 4u + r.
+__device__ __forceinline__ int perm_row(int c, int u, int i) { return 32 * c + 8 * (i >> 2) + 4 * u + (i & 3); }
+
+template <int DH> struct AttnDims {
+    static constexpr int KS = DH >= 32 ? DH / 32 : 1;   // 32-wide k-steps over the head dim
+    static constexpr int DT = DH >= 16 ? DH / 16 : 1;   // 16-wide output tiles over the head dim
+    static constexpr int DHV = DH >= 16 ? DH : 16;      // rows of a transposed [d][seq] image
+    static constexpr int LDR = DH + 8;                  // row stride of a [seq][d] image (elements)
+    static constexpr int CPR = DH / 8;                  // 16-byte chunks per row
+};
+
+// 16-byte fragment of row `row` of a [seq][DH] matrix in HBM (row stride ld), head-dim offset
+// ks*32 + 8*g; zero outside the matrix.
+template <int DH>
+__device__ __forceinline__ bf16x8 global_frag(const bf16_t* base, long long ld, int row, int nrows, int ks, int g) {
+    const int d = ks * 32 + g * 8;
+    if (row < nrows && d < DH) return *reinterpret_cast<const bf16x8*>(base + (long long)row * ld + d);
+    return zero8();
+}
+template <int DH>
+__device__ __forceinline__ bf16x8 lds_row_frag(const bf16_t* img, int row, int ks, int g) {
+    const int d = ks * 32 + g * 8;
+    if (d < DH) return *reinterpret_cast<const bf16x8*>(img + row * AttnDims<DH>::LDR + d);
+    return zero8();
+}
+
+// stage rows [0,NP) of a [seq][DH] HBM matrix into a row image and/or a transposed image
+template <int DH, int NP, bool ROWS, bool TRANS>
+__device__ __forceinline__ void stage(const bf16_t* src, long long ld, int n, bf16_t* rows_img, bf16_t* trans_img) {
+    using A = AttnDims<DH>;
+    constexpr int LDT = NP + 8;
+    for (int c = threadIdx.x; c < NP * A::CPR; c += blockDim.x) {
+        const int r = c / A::CPR, kc = c % A::CPR;
+        bf16x8 v = zero8();
+        if (r < n) v = *reinterpret_cast<const bf16x8*>(src + (long long)r * ld + kc * 8);
+        if (ROWS) *reinterpret_cast<bf16x8*>(rows_img + r * A::LDR + kc * 8) = v;
+        if (TRANS) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) trans_img[(kc * 8 + j) * LDT + r] = v[j];
+        }
+    }
+    if (TRANS && A::DHV > DH) {
+        for (int c = threadIdx.x; c < (A::DHV - DH) * LDT; c += blockDim.x) trans_img[DH * LDT + c] = (bf16_t)0.f;
+    }
+}
+
+// ================================================================ forward (bf16)
+template <int DH, int NC>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, bf16_t* __restrict__ probs, int N,
+                                                            int H, float scale) {
+    using A = AttnDims<DH>;
+    constexpr int NP = NC * 32, LDT = NP + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* VTs = Ks + NP * A::LDR;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
+    const bf16_t* kb = qb + I;
+    const bf16_t* vb = qb + 2 * I;
+    stage<DH, NP, true, false>(kb, ld, N, Ks, nullptr);
+    stage<DH, NP, false, true>(vb, ld, N, nullptr, VTs);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const float sl2 = scale * LOG2E;
+    for (int qt = wave; qt * 16 < N; qt += nwaves) {
+        const int q = qt * 16 + fr;
+        bf16x8 qf[A::KS];
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) qf[ks] = global_frag<DH>(qb, ld, q, N, ks, fg);
+        // S^T tiles: s[c][u][r] = score(query q, key 32c + 8fg + 4u + r)
+        f32x4 s[NC][2];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int krow = perm_row(c, u, fr);
+#pragma unroll
+                for (int ks = 0; ks < A::KS; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(Ks, krow, ks, fg), qf[ks], acc, 0, 0, 0);
+                s[c][u] = acc;
+            }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 32 * c + 8 * fg + 4 * u + r;
+                    if (key >= N) s[c][u][r] = -INFINITY;
+                    mx = fmaxf(mx, s[c][u][r]);
+                }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f((s[c][u][r] - mx) * sl2);
+                    s[c][u][r] = p;
+                    sum += p;
+                }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        if (fg == 0 && q < N) lse[((long long)b * H + h) * N + q] = mx * scale + logf(sum);
+        // O^T = V^T P^T, d-tile by d-tile
+        f32x4 o[A::DT];
+#pragma unroll
+        for (int dt = 0; dt < A::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            bf16x8 pf;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pf[4 * u + r] = (bf16_t)(s[c][u][r] * inv);
+            if (probs && q < N) {
+                bf16_t* prow = probs + (((long long)b * H + h) * N + q) * N;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int key = 32 * c + 8 * fg + j;
+                    if (key < N) prow[key] = pf[j];
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&VTs[(dt * 16 + fr) * LDT + 32 * c + 8 * fg]);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+            }
+        }
+        if (q < N) {
+            bf16_t* orow = out + ((long long)b * N + q) * I + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) {
+                const int d = dt * 16 + fg * 4;
+                if (d < DH) {
+                    bf16x4 pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)o[dt][r];
+                    *reinterpret_cast<bf16x4*>(orow + d) = pk;
+                }
+            }
+        }
+    }
+}
+
+// ================================================================ backward dK, dV (bf16)
+template <int DH, int NC>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
+                                                                const bf16_t* __restrict__ out,
+                                                                const bf16_t* __restrict__ dout,
+                                                                const float* __restrict__ lse,
+                                                                bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    using A = AttnDims<DH>;
+    constexpr int NP = NC * 32, LDT = NP + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* dOs = Qs + NP * A::LDR;
+    bf16_t* QTs = dOs + NP * A::LDR;
+    bf16_t* dOTs = QTs + A::DHV * LDT;
+    float* lse2 = reinterpret_cast<float*>(dOTs + A::DHV * LDT);
+    float* delta = lse2 + NP;
+
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
+    const bf16_t* kb = qb + I;
+    const bf16_t* vb = qb + 2 * I;
+    const bf16_t* ob = out + (long long)b * N * I + h * DH;
+    const bf16_t* dob = dout + (long long)b * N * I + h * DH;
+    stage<DH, NP, true, true>(qb, ld, N, Qs, QTs);
+    stage<DH, NP, true, true>(dob, I, N, dOs, dOTs);
+    // lse (in log2 units) and delta = rowsum(dO * O) per query; padded queries get p = 0
+    for (int q = threadIdx.x; q < NP; q += blockDim.x) {
+        float l2 = 1e30f, dl = 0.f;
+        if (q < N) {
+            l2 = lse[((long long)b * H + h) * N + q] * LOG2E;
+            for (int d = 0; d < DH; d += 8) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ob + (long long)q * I + d);
+                const bf16x8 g = *reinterpret_cast<const bf16x8*>(dob + (long long)q * I + d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
+            }
+        }
+        lse2[q] = l2;
+        delta[q] = dl;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const float sl2 = scale * LOG2E;
+    for (int kt = wave; kt * 16 < N; kt += nwaves) {
+        const int key = kt * 16 + fr;
+        bf16x8 kf[A::KS], vf[A::KS];
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) {
+            kf[ks] = global_frag<DH>(kb, ld, key, N, ks, fg);
+            vf[ks] = global_frag<DH>(vb, ld, key, N, ks, fg);
+        }
+        f32x4 dkt[A::DT], dvt[A::DT];
+#pragma unroll
+        for (int dt = 0; dt < A::DT; ++dt) dkt[dt] = dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int c = 0; c < NC; ++c) {
+            bf16x8 pf, dsf;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int qrow = perm_row(c, u, fr);
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < A::KS; ++ks) {
+                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(Qs, qrow, ks, fg), kf[ks], sa, 0, 0, 0);
+                    dpa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(dOs, qrow, ks, fg), vf[ks], dpa, 0, 0, 0);
+                }
+                // this lane's rows are queries 32c + 8fg + 4u + r
+                const int q0 = 32 * c + 8 * fg + 4 * u;
+                const f32x4 l2 = *reinterpret_cast<const f32x4*>(&lse2[q0]);
+                const f32x4 dl = *reinterpret_cast<const f32x4*>(&delta[q0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = exp2f(sa[r] * sl2 - l2[r]);
+                    pf[4 * u + r] = (bf16_t)p;
+                    dsf[4 * u + r] = (bf16_t)(p * (dpa[r] - dl[r]) * scale);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) {
+                const bf16x8 dof = *reinterpret_cast<const bf16x8*>(&dOTs[(dt * 16 + fr) * LDT + 32 * c + 8 * fg]);
+                const bf16x8 qtf = *reinterpret_cast<const bf16x8*>(&QTs[(dt * 16 + fr) * LDT + 32 * c + 8 * fg]);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dvt[dt], 0, 0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dkt[dt], 0, 0, 0);
+            }
+        }
+        if (key < N) {
+            bf16_t* dk = dqkv + ((long long)b * N + key) * ld + I + h * DH;
+            bf16_t* dv = dk + I;
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) {
+                const int d = dt * 16 + fg * 4;
+                if (d < DH) {
+                    bf16x4 a, c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        a[r] = (bf16_t)dkt[dt][r];
+                        c[r] = (bf16_t)dvt[dt][r];
+                    }
+                    *reinterpret_cast<bf16x4*>(dk + d) = a;
+                    *reinterpret_cast<bf16x4*>(dv + d) = c;
+                }
+            }
+        }
+    }
+}
+
+// ================================================================ backward dQ (bf16)
+template <int DH, int NC>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
+                                                               const bf16_t* __restrict__ out,
+                                                               const bf16_t* __restrict__ dout,
+                                                               const float* __restrict__ lse,
+                                                               bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+    using A = AttnDims<DH>;
+    constexpr int NP = NC * 32, LDT = NP + 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vs = Ks + NP * A::LDR;
+    bf16_t* KTs = Vs + NP * A::LDR;
+
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
+    const bf16_t* kb = qb + I;
+    const bf16_t* vb = qb + 2 * I;
+    const bf16_t* ob = out + (long long)b * N * I + h * DH;
+    const bf16_t* dob = dout + (long long)b * N * I + h * DH;
+    stage<DH, NP, true, true>(kb, ld, N, Ks, KTs);
+    stage<DH, NP, true, false>(vb, ld, N, Vs, nullptr);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const float sl2 = scale * LOG2E;
+    for (int qt = wave; qt * 16 < N; qt += nwaves) {
+        const int q = qt * 16 + fr;
+        bf16x8 qf[A::KS], dof[A::KS];
+        float dl = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) {
+            qf[ks] = global_frag<DH>(qb, ld, q, N, ks, fg);
+            dof[ks] = global_frag<DH>(dob, I, q, N, ks, fg);
+            const bf16x8 of = global_frag<DH>(ob, I, q, N, ks, fg);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dl += (float)of[j] * (float)dof[ks][j];
+        }
+        dl += __shfl_xor(dl, 16, 64);
+        dl += __shfl_xor(dl, 32, 64);
+        const float l2 = q < N ? lse[((long long)b * H + h) * N + q] * LOG2E : 1e30f;
+        f32x4 dqt[A::DT];
+#pragma unroll
+        for (int dt = 0; dt < A::DT; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int c = 0; c < NC; ++c) {
+            bf16x8 dsf;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int krow = perm_row(c, u, fr);
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < A::KS; ++ks) {
+                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(Ks, krow, ks, fg), qf[ks], sa, 0, 0, 0);
+                    dpa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(Vs, krow, ks, fg), dof[ks], dpa, 0, 0, 0);
+                }
+                // this lane's rows are keys 32c + 8fg + 4u + r; padded keys contribute nothing
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 32 * c + 8 * fg + 4 * u + r;
+                    const float p = key < N ? exp2f(sa[r] * sl2 - l2) : 0.f;
+                    dsf[4 * u + r] = (bf16_t)(p * (dpa[r] - dl) * scale);
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) {
+                const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(&KTs[(dt * 16 + fr) * LDT + 32 * c + 8 * fg]);
+                dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dqt[dt], 0, 0, 0);
+            }
+        }
+        if (q < N) {
+            bf16_t* dq = dqkv + ((long long)b * N + q) * ld + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) {
+                const int d = dt * 16 + fg * 4;
+                if (d < DH) {
+                    bf16x4 a;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a[r] = (bf16_t)dqt[dt][r];
+                    *reinterpret_cast<bf16x4*>(dq + d) = a;
+                }
+            }
+        }
+    }
+}
+
+// ================================================================ fp32 path
+// forward: block per (b,h), K and V in LDS, one wave per query row.
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           float* __restrict__ lse, float* __restrict__ probs, int N,
+                                                           int H, int DH, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);        // [N][DH+1]
+    float* Vs = Ks + (long long)N * (DH + 1);          // [N][DH+1]
+    float* qs = Vs + (long long)N * (DH + 1);          // [4][DH]
+    float* ps = qs + 4 * DH;                           // [4][N]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const float* qb = qkv + (long long)b * N * ld + h * DH;
+    for (int c = threadIdx.x; c < N * DH; c += blockDim.x) {
+        const int r = c / DH, d = c % DH;
+        Ks[r * (DH + 1) + d] = qb[(long long)r * ld + I + d];
+        Vs[r * (DH + 1) + d] = qb[(long long)r * ld + 2 * I + d];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* myq = qs + wave * DH;
+    float* myp = ps + wave * N;
+    for (int q = wave; q < N; q += 4) {
+        for (int d = lane; d < DH; d += 64) myq[d] = qb[(long long)q * ld + d];
+        __builtin_amdgcn_wave_barrier();
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = lane + 64 * t;
+            float s = -INFINITY;
+            if (j < N) {
+                s = 0.f;
+                for (int d = 0; d < DH; ++d) s = fmaf(myq[d], Ks[j * (DH + 1) + d], s);
+                s *= scale;
+            }
+            sc[t] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            sc[t] = (lane + 64 * t < N) ? expf(sc[t] - mx) : 0.f;
+            sum += sc[t];
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = lane + 64 * t;
+            if (j < N) {
+                const float p = sc[t] * inv;
+                myp[j] = p;
+                if (probs) probs[(((long long)b * H + h) * N + q) * N + j] = p;
+            }
+        }
+        if (lane == 0) lse[((long long)b * H + h) * N + q] = mx + logf(sum);
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < DH; d += 64) {
+            float o = 0.f;
+            for (int j = 0; j < N; ++j) o = fmaf(myp[j], Vs[j * (DH + 1) + d], o);
+            out[((long long)b * N + q) * I + h * DH + d] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// backward pass 1: per query row -> dq, and P, dS rows into the workspace
+__global__ __launch_bounds__(256) void attn_bwd_q_f32_kernel(const float* __restrict__ qkv,
+                                                             const float* __restrict__ dout,
+                                                             const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                             float* __restrict__ Pw, float* __restrict__ dSw, int N,
+                                                             int H, int DH, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);
+    float* Vs = Ks + (long long)N * (DH + 1);
+    float* qs = Vs + (long long)N * (DH + 1);   // [4][2*DH]: q row then dO row
+    float* ds = qs + 4 * 2 * DH;                // [4][N]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const float* qb = qkv + (long long)b * N * ld + h * DH;
+    const float* dob = dout + (long long)b * N * I + h * DH;
+    for (int c = threadIdx.x; c < N * DH; c += blockDim.x) {
+        const int r = c / DH, d = c % DH;
+        Ks[r * (DH + 1) + d] = qb[(long long)r * ld + I + d];
+        Vs[r * (DH + 1) + d] = qb[(long long)r * ld + 2 * I + d];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* myq = qs + wave * 2 * DH;
+    float* mydo = myq + DH;
+    float* myds = ds + wave * N;
+    for (int q = wave; q < N; q += 4) {
+        for (int d = lane; d < DH; d += 64) {
+            myq[d] = qb[(long long)q * ld + d];
+            mydo[d] = dob[(long long)q * I + d];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float l = lse[((long long)b * H + h) * N + q];
+        float p[4], dp[4];
+        float dsum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = lane + 64 * t;
+            p[t] = dp[t] = 0.f;
+            if (j < N) {
+                float s = 0.f, g = 0.f;
+                for (int d = 0; d < DH; ++d) {
+                    s = fmaf(myq[d], Ks[j * (DH + 1) + d], s);
+                    g = fmaf(mydo[d], Vs[j * (DH + 1) + d], g);
+                }
+                p[t] = expf(s * scale - l);
+                dp[t] = g;
+                dsum += p[t] * g;
+            }
+        }
+        dsum = wave_sum(dsum);
+        const long long rowoff = (((long long)b * H + h) * N + q) * N;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = lane + 64 * t;
+            if (j < N) {
+                const float dsv = p[t] * (dp[t] - dsum) * scale;
+                myds[j] = dsv;
+                Pw[rowoff + j] = p[t];
+                dSw[rowoff + j] = dsv;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < DH; d += 64) {
+            float o = 0.f;
+            for (int j = 0; j < N; ++j) o = fmaf(myds[j], Ks[j * (DH + 1) + d], o);
+            dqkv[((long long)b * N + q) * ld + h * DH + d] = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// backward pass 2: per key row -> dk, dv from the stored P and dS columns
+__global__ __launch_bounds__(256) void attn_bwd_kv_f32_kernel(const float* __restrict__ qkv,
+                                                              const float* __restrict__ dout,
+                                                              const float* __restrict__ Pw,
+                                                              const float* __restrict__ dSw, float* __restrict__ dqkv,
+                                                              int N, int H, int DH) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Qs = reinterpret_cast<float*>(smem);     // [N][DH+1]
+    float* dOs = Qs + (long long)N * (DH + 1);      // [N][DH+1]
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const float* qb = qkv + (long long)b * N * ld + h * DH;
+    const float* dob = dout + (long long)b * N * I + h * DH;
+    for (int c = threadIdx.x; c < N * DH; c += blockDim.x) {
+        const int r = c / DH, d = c % DH;
+        Qs[r * (DH + 1) + d] = qb[(long long)r * ld + d];
+        dOs[r * (DH + 1) + d] = dob[(long long)r * I + d];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long headoff = ((long long)b * H + h) * N * N;
+    for (int j = wave; j < N; j += 4) {
+        for (int d = lane; d < DH; d += 64) {
+            float dk = 0.f, dv = 0.f;
+            for (int q = 0; q < N; ++q) {
+                const float p = Pw[headoff + (long long)q * N + j];
+                const float s = dSw[headoff + (long long)q * N + j];
+                dv = fmaf(p, dOs[q * (DH + 1) + d], dv);
+                dk = fmaf(s, Qs[q * (DH + 1) + d], dk);
+            }
+            dqkv[((long long)b * N + j) * ld + I + h * DH + d] = dk;
+            dqkv[((long long)b * N + j) * ld + 2 * I + h * DH + d] = dv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- dispatch helpers
+inline int pick_nc(int N) {
+    const int need = (N + 31) / 32;
+    const int avail[] = {2, 3, 4, 7, 8};
+    for (int a : avail)
+        if (need <= a) return a;
+    return 0;
+}
+
+template <int DH, int NC>
+size_t dkv_smem() {
+    using A = AttnDims<DH>;
+    constexpr int NP = NC * 32, LDT = NP + 8;
+    return (size_t)(2 * NP * A::LDR + 2 * A::DHV * LDT) * sizeof(bf16_t) + 2 * NP * sizeof(float);
+}
+template <int DH, int NC>
+size_t dq_smem() {
+    using A = AttnDims<DH>;
+    constexpr int NP = NC * 32, LDT = NP + 8;
+    return (size_t)(2 * NP * A::LDR + A::DHV * LDT) * sizeof(bf16_t);
+}
+
+// Raise a kernel's dynamic-LDS limit once per device (the attribute is per device; one process
+// may drive several devices from several threads).
+inline int ensure_lds(const void* fn, size_t bytes, unsigned long long* done_mask, const char* who) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return vitmi_hip_fail(e, who);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return VITMI_OK;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return vitmi_hip_fail(e, who);
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+    return VITMI_OK;
+}
+
+template <int DH, int NC>
+size_t fwd_smem() {
+    using A = AttnDims<DH>;
+    constexpr int NP = NC * 32, LDT = NP + 8;
+    return (size_t)(NP * A::LDR + A::DHV * LDT) * sizeof(bf16_t);
+}
+
+template <int DH, int NC>
+int launch_fwd(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
+    const float scale = 1.0f / sqrtf((float)DH);
+    static unsigned long long done = 0;
+    const size_t sm = fwd_smem<DH, NC>();
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH, NC>), sm, &done, "vitmi_attn_fwd: LDS attribute");
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC>), dim3(B * H), dim3(256), sm, s, (const bf16_t*)qkv, (bf16_t*)out,
+                       lse, (bf16_t*)probs, N, H, scale);
+    VITMI_LAUNCH_CHECK("vitmi_attn_fwd(bf16)");
+    return VITMI_OK;
+}
+
+template <int DH, int NC>
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N, int H,
+               hipStream_t s) {
+    const float scale = 1.0f / sqrtf((float)DH);
+    static unsigned long long done1 = 0, done2 = 0;
+    const size_t s1 = dkv_smem<DH, NC>(), s2 = dq_smem<DH, NC>();
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_dkv_bf16_kernel<DH, NC>), s1, &done1, "vitmi_attn_bwd: LDS attribute (dkv)");
+    if (rc != VITMI_OK) return rc;
+    rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_dq_bf16_kernel<DH, NC>), s2, &done2, "vitmi_attn_bwd: LDS attribute (dq)");
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DH, NC>), dim3(B * H), dim3(256), s1, s, (const bf16_t*)qkv,
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
+    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dkv, bf16)");
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DH, NC>), dim3(B * H), dim3(256), s2, s, (const bf16_t*)qkv,
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
+    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dq, bf16)");
+    return VITMI_OK;
+}
+
+#define DISPATCH_NC(FN, DH, ...)                      \
+    switch (nc) {                                     \
+        case 2: return FN<DH, 2>(__VA_ARGS__);        \
+        case 3: return FN<DH, 3>(__VA_ARGS__);        \
+        case 4: return FN<DH, 4>(__VA_ARGS__);        \
+        case 7: return FN<DH, 7>(__VA_ARGS__);        \
+        default: return FN<DH, 8>(__VA_ARGS__);       \
+    }
+
+inline size_t f32_fwd_smem(int N, int DH) { return ((size_t)2 * N * (DH + 1) + 4 * DH + 4 * N) * sizeof(float); }
+inline size_t f32_bwdq_smem(int N, int DH) { return ((size_t)2 * N * (DH + 1) + 8 * DH + 4 * N) * sizeof(float); }
+inline size_t f32_bwdkv_smem(int N, int DH) { return ((size_t)2 * N * (DH + 1)) * sizeof(float); }
+
+int check_common(const char* who, int dt, int B, int N, int H, int DH) {
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "%s: bad dtype %d", who, dt);
+    VITMI_CHECK_ARG(B > 0 && N > 0 && H > 0 && DH > 0, "%s: bad shape B=%d N=%d H=%d DH=%d", who, B, N, H, DH);
+    if (N > 256) {
+        vitmi_set_error("%s: sequence length N=%d exceeds the supported 256 tokens", who, N);
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    if (dt == VITMI_BF16 && !(DH == 8 || DH == 16 || DH == 32 || DH == 64)) {
+        vitmi_set_error("%s: bf16 head dim %d not in {8,16,32,64}", who, DH);
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    if (dt == VITMI_F32 && f32_bwdq_smem(N, DH) > 160 * 1024) {
+        vitmi_set_error("%s: fp32 path needs %zu B of LDS for N=%d DH=%d (limit 163840)", who, f32_bwdq_smem(N, DH), N,
+                        DH);
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    return VITMI_OK;
+}
+
+}  // namespace
+
+extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, int B, int N, int H, int DH,
+                              void* stream) {
+    VITMI_CHECK_ARG(qkv && out && lse, "vitmi_attn_fwd: null pointer");
+    int rc = check_common("vitmi_attn_fwd", dt, B, N, H, DH);
+    if (rc != VITMI_OK) return rc;
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_ATTN_FWD, s, 4.0 * B * H * (double)N * N * DH);
+    if (dt == VITMI_F32) {
+        const size_t sm = f32_fwd_smem(N, DH);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vitmi_hip_fail(e, "vitmi_attn_fwd: hipFuncSetAttribute");
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(B * H), dim3(256), sm, s, (const float*)qkv, (float*)out, lse,
+                           (float*)probs, N, H, DH, 1.0f / sqrtf((float)DH));
+        VITMI_LAUNCH_CHECK("vitmi_attn_fwd(f32)");
+        return VITMI_OK;
+    }
+    const int nc = pick_nc(N);
+    switch (DH) {
+        case 8: DISPATCH_NC(launch_fwd, 8, qkv, out, lse, probs, B, N, H, s)
+        case 16: DISPATCH_NC(launch_fwd, 16, qkv, out, lse, probs, B, N, H, s)
+        case 32: DISPATCH_NC(launch_fwd, 32, qkv, out, lse, probs, B, N, H, s)
+        default: DISPATCH_NC(launch_fwd, 64, qkv, out, lse, probs, B, N, H, s)
+    }
+}
+
+extern "C" long long vitmi_attn_bwd_workspace_bytes(int dt, int B, int N, int H, int DH) {
+    (void)DH;
+    if (dt == VITMI_F32) return 2ll * B * H * N * N * (long long)sizeof(float);
+    return 0;
+}
+
+extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const void* dprobs,
+                              void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, void* stream) {
+    VITMI_CHECK_ARG(qkv && out && dout && lse && dqkv, "vitmi_attn_bwd: null pointer");
+    int rc = check_common("vitmi_attn_bwd", dt, B, N, H, DH);
+    if (rc != VITMI_OK) return rc;
+    if (dprobs) {
+        vitmi_set_error("vitmi_attn_bwd: a gradient flowing into the exported probabilities is not supported");
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = as_stream(stream);
+    // five products of the flash-style backward: 10 * B * H * N^2 * DH
+    ProfScope prof(VITMI_FAM_ATTN_BWD, s, 10.0 * B * H * (double)N * N * DH);
+    if (dt == VITMI_F32) {
+        VITMI_CHECK_ARG(workspace, "vitmi_attn_bwd: fp32 path needs a workspace");
+        float* Pw = (float*)workspace;
+        float* dSw = Pw + (long long)B * H * N * N;
+        const size_t s1 = f32_bwdq_smem(N, DH), s2 = f32_bwdkv_smem(N, DH);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_f32_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vitmi_hip_fail(e, "vitmi_attn_bwd: hipFuncSetAttribute");
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_f32_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return vitmi_hip_fail(e, "vitmi_attn_bwd: hipFuncSetAttribute");
+        const float scale = 1.0f / sqrtf((float)DH);
+        hipLaunchKernelGGL(attn_bwd_q_f32_kernel, dim3(B * H), dim3(256), s1, s, (const float*)qkv, (const float*)dout,
+                           lse, (float*)dqkv, Pw, dSw, N, H, DH, scale);
+        VITMI_LAUNCH_CHECK("vitmi_attn_bwd(q, f32)");
+        hipLaunchKernelGGL(attn_bwd_kv_f32_kernel, dim3(B * H), dim3(256), s2, s, (const float*)qkv, (const float*)dout,
+                           Pw, dSw, (float*)dqkv, N, H, DH);
+        VITMI_LAUNCH_CHECK("vitmi_attn_bwd(kv, f32)");
+        return VITMI_OK;
+    }
+    const int nc = pick_nc(N);
+    switch (DH) {
+        case 8: DISPATCH_NC(launch_bwd, 8, qkv, out, dout, lse, dqkv, B, N, H, s)
+        case 16: DISPATCH_NC(launch_bwd, 16, qkv, out, dout, lse, dqkv, B, N, H, s)
+        case 32: DISPATCH_NC(launch_bwd, 32, qkv, out, dout, lse, dqkv, B, N, H, s)
+        default: DISPATCH_NC(launch_bwd, 64, qkv, out, dout, lse, dqkv, B, N, H, s)
+    }
+}

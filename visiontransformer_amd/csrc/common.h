@@ -1,0 +1,82 @@
+// Shared device/host helpers for the gfx950 ViT encoder kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vitmi.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+// ---- error plumbing -------------------------------------------------------------------------
+void vitmi_set_error(const char* fmt, ...);
+int vitmi_hip_fail(hipError_t e, const char* what);
+
+#define VITMI_CHECK_ARG(cond, ...)                  \
+    do {                                            \
+        if (!(cond)) {                              \
+            vitmi_set_error(__VA_ARGS__);           \
+            return VITMI_ERR_BAD_ARG;               \
+        }                                           \
+    } while (0)
+
+#define VITMI_LAUNCH_CHECK(name)                                  \
+    do {                                                          \
+        hipError_t e__ = hipGetLastError();                       \
+        if (e__ != hipSuccess) return vitmi_hip_fail(e__, name);  \
+    } while (0)
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- per-kernel-family launch timing (drives bench.py's roofline object) ---------------------
+void vitmi_prof_record_begin(int family, hipStream_t s, double work);
+void vitmi_prof_record_end(int family, hipStream_t s);
+
+struct ProfScope {
+    int fam;
+    hipStream_t s;
+    ProfScope(int family, hipStream_t st, double work) : fam(family), s(st) { vitmi_prof_record_begin(fam, s, work); }
+    ~ProfScope() { vitmi_prof_record_end(fam, s); }
+};
+
+// ---- dtype traits --------------------------------------------------------------------------
+template <typename T> struct dt_of;
+template <> struct dt_of<float> { static constexpr int value = VITMI_F32; };
+template <> struct dt_of<bf16_t> { static constexpr int value = VITMI_BF16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU and its derivative (nn.GELU() default form)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}

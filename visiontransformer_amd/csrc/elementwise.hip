@@ -1,0 +1,681 @@
+// HBM-bound kernels of the ViT encoder path: casts, residual adds, column sums, token
+// assembly with (gathered) positional embedding, LayerNorm forward/backward, mean pooling,
+// fused Adam.  All are coalesced row/stream kernels: 8-16 B per lane, one wave per token row
+// where a row reduction is needed, fp32 arithmetic, deterministic two-stage reductions.
+#include "common.h"
+
+namespace {
+
+template <typename T, int V> struct Vec { T v[V]; };
+
+template <typename T, int V>
+__device__ __forceinline__ void load_vec(const T* p, float (&f)[V]) {
+    typedef Vec<T, V> __attribute__((aligned(sizeof(T) * V))) VT;
+    VT t = *reinterpret_cast<const VT*>(p);
+#pragma unroll
+    for (int i = 0; i < V; ++i) f[i] = to_f32(t.v[i]);
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_vec(T* p, const float (&f)[V]) {
+    typedef Vec<T, V> __attribute__((aligned(sizeof(T) * V))) VT;
+    VT t;
+#pragma unroll
+    for (int i = 0; i < V; ++i) t.v[i] = from_f32<T>(f[i]);
+    *reinterpret_cast<VT*>(p) = t;
+}
+
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// ---------------------------------------------------------------- cast / add
+template <typename S, typename D, int V>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, long long n) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const long long stride = (long long)gridDim.x * blockDim.x * V;
+    for (; i + V <= n; i += stride) {
+        float f[V];
+        load_vec<S, V>(src + i, f);
+        store_vec<D, V>(dst + i, f);
+    }
+    if (i < n && i + V > n) {
+        for (long long j = i; j < n; ++j) dst[j] = from_f32<D>(to_f32(src[j]));
+    }
+}
+
+template <typename S, typename D>
+int launch_cast(const void* src, void* dst, long long n, hipStream_t s) {
+    if (n == 0) return VITMI_OK;
+    const bool vec = aligned_to(src, 16) && aligned_to(dst, 16);
+    const int threads = 256;
+    if (vec) {
+        constexpr int V = 4;
+        int blocks = (int)std::min<long long>((n + threads * V - 1) / (threads * V), 4096);
+        hipLaunchKernelGGL((cast_kernel<S, D, V>), dim3(blocks), dim3(threads), 0, s, (const S*)src, (D*)dst, n);
+    } else {
+        int blocks = (int)std::min<long long>((n + threads - 1) / threads, 4096);
+        hipLaunchKernelGGL((cast_kernel<S, D, 1>), dim3(blocks), dim3(threads), 0, s, (const S*)src, (D*)dst, n);
+    }
+    VITMI_LAUNCH_CHECK("vitmi_cast");
+    return VITMI_OK;
+}
+
+template <typename T, int V>
+__global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, long long n) {
+    long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const long long stride = (long long)gridDim.x * blockDim.x * V;
+    for (; i + V <= n; i += stride) {
+        float fa[V], fb[V];
+        load_vec<T, V>(a + i, fa);
+        load_vec<T, V>(b + i, fb);
+#pragma unroll
+        for (int j = 0; j < V; ++j) fa[j] += fb[j];
+        store_vec<T, V>(y + i, fa);
+    }
+    if (i < n && i + V > n) {
+        for (long long j = i; j < n; ++j) y[j] = from_f32<T>(to_f32(a[j]) + to_f32(b[j]));
+    }
+}
+
+// ---------------------------------------------------------------- column sums
+// stage 1: block (strip, chunk): partial[chunk][c] = sum over the chunk's rows; lane owns V
+// adjacent columns, the 4 waves of a block interleave rows and combine through LDS.
+template <typename T, int V>
+__global__ void colsum_partial_kernel(const T* __restrict__ x, long long rows, int cols, long long ld,
+                                      float* __restrict__ partial, int rows_per_chunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + lane) * V;
+    const long long r_begin = (long long)blockIdx.y * rows_per_chunk;
+    const long long r_end = r_begin + rows_per_chunk < rows ? r_begin + rows_per_chunk : rows;
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+    if (c0 < cols) {
+        for (long long r = r_begin + wave; r < r_end; r += 4) {
+            if (V > 1) {
+                float f[V];
+                load_vec<T, V>(x + r * ld + c0, f);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += f[j];
+            } else {
+                acc[0] += to_f32(x[r * ld + c0]);
+            }
+        }
+    }
+    __shared__ float red[4][64 * V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[wave][lane * V + j] = acc[j];
+    __syncthreads();
+    if (wave == 0 && c0 < cols) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float s = red[0][lane * V + j] + red[1][lane * V + j] + red[2][lane * V + j] + red[3][lane * V + j];
+            partial[(long long)blockIdx.y * cols + c0 + j] = s;
+        }
+    }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += partial[(long long)k * cols + c];
+    out[c] = s;
+}
+
+inline int colsum_chunks(long long rows) {
+    long long c = (rows + 255) / 256;
+    if (c > 128) c = 128;
+    if (c < 1) c = 1;
+    return (int)c;
+}
+
+template <typename T>
+int launch_colsum(const void* x, long long rows, int cols, long long ld, float* out, void* workspace, hipStream_t s) {
+    const int chunks = colsum_chunks(rows);
+    const int rows_per_chunk = (int)((rows + chunks - 1) / chunks);
+    float* partial = (float*)workspace;
+    const bool vec = (cols % 4 == 0) && (ld % 4 == 0) && aligned_to(x, 16);
+    if (vec) {
+        dim3 grid(ceil_div(cols, 64 * 4), chunks);
+        hipLaunchKernelGGL((colsum_partial_kernel<T, 4>), grid, dim3(256), 0, s, (const T*)x, rows, cols, ld, partial,
+                           rows_per_chunk);
+    } else {
+        dim3 grid(ceil_div(cols, 64), chunks);
+        hipLaunchKernelGGL((colsum_partial_kernel<T, 1>), grid, dim3(256), 0, s, (const T*)x, rows, cols, ld, partial,
+                           rows_per_chunk);
+    }
+    VITMI_LAUNCH_CHECK("vitmi_colsum(partial)");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, s, partial, chunks, cols, out);
+    VITMI_LAUNCH_CHECK("vitmi_colsum(final)");
+    return VITMI_OK;
+}
+
+// ---------------------------------------------------------------- token assembly (+ gathered PE)
+// one wave per output token row; lanes sweep the row V elements at a time.
+template <typename T, int V>
+__global__ void tokens_assemble_fwd_kernel(const T* __restrict__ patch, const float* __restrict__ cls,
+                                           const float* __restrict__ pe, const long long* __restrict__ seq_ord,
+                                           T* __restrict__ out, int B, int N, int D) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= (long long)B * N) return;
+    const int b = (int)(row / N), i = (int)(row % N);
+    // a negative index means "no positional row for this token" (zero embedding)
+    const long long pr = pe ? (seq_ord ? seq_ord[i] : (long long)i) : -1;
+    const float* pe_row = pr >= 0 ? pe + pr * D : nullptr;
+    T* o = out + row * D;
+    const T* src = i > 0 ? patch + ((long long)b * (N - 1) + (i - 1)) * D : nullptr;
+    for (int c = lane * V; c < D; c += 64 * V) {
+        float f[V];
+        if (i > 0) {
+            load_vec<T, V>(src + c, f);
+        } else {
+            load_vec<float, V>(cls + c, f);
+        }
+        if (pe_row) {
+            float p[V];
+            load_vec<float, V>(pe_row + c, p);
+#pragma unroll
+            for (int j = 0; j < V; ++j) f[j] += p[j];
+        }
+        store_vec<T, V>(o + c, f);
+    }
+}
+
+// dpe[r,:] = sum over positions i (ascending) with row(i) == r of possum[i,:]; dcls = possum[0,:]
+__global__ void tokens_scatter_rows_kernel(const float* __restrict__ possum, const long long* __restrict__ seq_ord,
+                                           float* __restrict__ dcls, float* __restrict__ dpe, int pe_rows, int N,
+                                           int D) {
+    const int r = blockIdx.x;  // r == pe_rows -> the cls-gradient block
+    if (r == pe_rows) {
+        for (int c = threadIdx.x; c < D; c += blockDim.x) dcls[c] = possum[c];
+        return;
+    }
+    if (!dpe) return;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float s = 0.f;
+        for (int i = 0; i < N; ++i) {
+            const long long row = seq_ord ? seq_ord[i] : (long long)i;
+            if (row == r) s += possum[(long long)i * D + c];
+        }
+        dpe[(long long)r * D + c] = s;
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm
+// ITERS = ceil(D / (64*V)) is a template parameter so the per-lane row slice stays in registers.
+
+template <typename T, int V, int LN_MAX_ITERS>
+__global__ void layernorm_fwd_kernel(const T* __restrict__ x, long long ldx, const float* __restrict__ gamma,
+                                     const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
+                                     float* __restrict__ rstd, long long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * ldx;
+    float v[LN_MAX_ITERS][V];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_ITERS; ++it) {
+        const int c = (it * 64 + lane) * V;
+        if (c < D) {
+            load_vec<T, V>(xr + c, v[it]);
+#pragma unroll
+            for (int j = 0; j < V; ++j) s += v[it][j];
+        }
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_ITERS; ++it) {
+        const int c = (it * 64 + lane) * V;
+        if (c < D) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float d = v[it][j] - mu;
+                q += d * d;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+    T* yr = y + row * (long long)D;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_ITERS; ++it) {
+        const int c = (it * 64 + lane) * V;
+        if (c < D) {
+            float g[V], bt[V], o[V];
+            load_vec<float, V>(gamma + c, g);
+            load_vec<float, V>(beta + c, bt);
+#pragma unroll
+            for (int j = 0; j < V; ++j) o[j] = (v[it][j] - mu) * rs * g[j] + bt[j];
+            store_vec<T, V>(yr + c, o);
+        }
+    }
+}
+
+// each wave walks rows (grid-strided), keeps its columns' dgamma/dbeta partial sums in
+// registers, and the block writes one partial row pair; a second kernel adds the partials in
+// block order.
+template <typename T, int V, int LN_MAX_ITERS>
+__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long long ldx,
+                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, const T* __restrict__ dres, T* __restrict__ dx,
+                                     float* __restrict__ partial, long long rows, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    float dg[LN_MAX_ITERS][V], db[LN_MAX_ITERS][V], gm[LN_MAX_ITERS][V];
+#pragma unroll
+    for (int it = 0; it < LN_MAX_ITERS; ++it) {
+        const int c = (it * 64 + lane) * V;
+#pragma unroll
+        for (int j = 0; j < V; ++j) dg[it][j] = db[it][j] = gm[it][j] = 0.f;
+        if (c < D) load_vec<float, V>(gamma + c, gm[it]);
+    }
+    for (long long row = (long long)blockIdx.x * nw + wave; row < rows; row += (long long)gridDim.x * nw) {
+        const T* xr = x + row * ldx;
+        const T* dyr = dy + row * (long long)D;
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAX_ITERS][V], g[LN_MAX_ITERS][V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < LN_MAX_ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
+            if (c < D) {
+                float xv[V], dv[V];
+                load_vec<T, V>(xr + c, xv);
+                load_vec<T, V>(dyr + c, dv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    xh[it][j] = (xv[j] - mu) * rs;
+                    g[it][j] = dv[j] * gm[it][j];
+                    s1 += g[it][j];
+                    s2 += g[it][j] * xh[it][j];
+                    dg[it][j] += dv[j] * xh[it][j];
+                    db[it][j] += dv[j];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+        T* dxr = dx + row * (long long)D;
+#pragma unroll
+        for (int it = 0; it < LN_MAX_ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
+            if (c < D) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) o[j] = rs * (g[it][j] - c1 - xh[it][j] * c2);
+                if (dres) {
+                    float r[V];
+                    load_vec<T, V>(dres + row * (long long)D + c, r);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) o[j] += r[j];
+                }
+                store_vec<T, V>(dxr + c, o);
+            }
+        }
+    }
+    // combine the block's waves through LDS, one iteration slice at a time
+    __shared__ float red[2][4][64 * V];
+#pragma unroll
+    for (int it = 0; it < LN_MAX_ITERS; ++it) {
+        if (it * 64 * V >= D) break;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            red[0][wave][lane * V + j] = dg[it][j];
+            red[1][wave][lane * V + j] = db[it][j];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            const int c = (it * 64 + lane) * V;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    float a = 0.f, b = 0.f;
+                    for (int w = 0; w < nw; ++w) {
+                        a += red[0][w][lane * V + j];
+                        b += red[1][w][lane * V + j];
+                    }
+                    partial[((long long)blockIdx.x * 2 + 0) * D + c + j] = a;
+                    partial[((long long)blockIdx.x * 2 + 1) * D + c + j] = b;
+                }
+            }
+        }
+    }
+}
+
+__global__ void layernorm_bwd_final_kernel(const float* __restrict__ partial, int blocks, int D,
+                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < blocks; ++k) {
+        a += partial[((long long)k * 2 + 0) * D + c];
+        b += partial[((long long)k * 2 + 1) * D + c];
+    }
+    if (dgamma) dgamma[c] = a;
+    if (dbeta) dbeta[c] = b;
+}
+
+inline int ln_bwd_blocks(long long rows) {
+    long long b = (rows + 3) / 4;
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- mean pooling
+template <typename T>
+__global__ void meanpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int N, int D) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * D) return;
+    const int b = (int)(idx / D), c = (int)(idx % D);
+    float s = 0.f;
+    for (int i = 0; i < N; ++i) s += to_f32(x[((long long)b * N + i) * D + c]);
+    out[idx] = from_f32<T>(s / (float)N);
+}
+template <typename T>
+__global__ void meanpool_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int B, int N, int D) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * N * D) return;
+    const int c = (int)(idx % D);
+    const int b = (int)(idx / ((long long)N * D));
+    dx[idx] = from_f32<T>(to_f32(dout[(long long)b * D + c]) / (float)N);
+}
+
+// ---------------------------------------------------------------- Adam
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, bf16_t* __restrict__ p16, long long n, float lr, float b1, float b2,
+                            float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float gi = g[i] * gscale;
+        float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+        if (p16) p16[i] = (bf16_t)pi;
+    }
+}
+
+}  // namespace
+
+// ================================================================ C ABI
+extern "C" int vitmi_cast(const void* src, int src_dt, void* dst, int dst_dt, long long n, void* stream) {
+    VITMI_CHECK_ARG(n >= 0 && (n == 0 || (src && dst)), "vitmi_cast: null pointer or negative n");
+    hipStream_t s = as_stream(stream);
+    if (src_dt == VITMI_F32 && dst_dt == VITMI_BF16) return launch_cast<float, bf16_t>(src, dst, n, s);
+    if (src_dt == VITMI_BF16 && dst_dt == VITMI_F32) return launch_cast<bf16_t, float>(src, dst, n, s);
+    if (src_dt == VITMI_F32 && dst_dt == VITMI_F32) return launch_cast<float, float>(src, dst, n, s);
+    if (src_dt == VITMI_BF16 && dst_dt == VITMI_BF16) return launch_cast<bf16_t, bf16_t>(src, dst, n, s);
+    vitmi_set_error("vitmi_cast: unsupported dtype pair %d -> %d", src_dt, dst_dt);
+    return VITMI_ERR_BAD_ARG;
+}
+
+extern "C" int vitmi_add(const void* a, const void* b, void* y, int dt, long long n, void* stream) {
+    VITMI_CHECK_ARG(n >= 0 && (n == 0 || (a && b && y)), "vitmi_add: null pointer or negative n");
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_add: bad dtype %d", dt);
+    if (n == 0) return VITMI_OK;
+    hipStream_t s = as_stream(stream);
+    const bool vec = aligned_to(a, 16) && aligned_to(b, 16) && aligned_to(y, 16);
+    const int threads = 256;
+    if (dt == VITMI_F32) {
+        if (vec) {
+            int blocks = (int)std::min<long long>((n + threads * 4 - 1) / (threads * 4), 4096);
+            hipLaunchKernelGGL((add_kernel<float, 4>), dim3(blocks), dim3(threads), 0, s, (const float*)a,
+                               (const float*)b, (float*)y, n);
+        } else {
+            int blocks = (int)std::min<long long>((n + threads - 1) / threads, 4096);
+            hipLaunchKernelGGL((add_kernel<float, 1>), dim3(blocks), dim3(threads), 0, s, (const float*)a,
+                               (const float*)b, (float*)y, n);
+        }
+    } else {
+        if (vec) {
+            int blocks = (int)std::min<long long>((n + threads * 8 - 1) / (threads * 8), 4096);
+            hipLaunchKernelGGL((add_kernel<bf16_t, 8>), dim3(blocks), dim3(threads), 0, s, (const bf16_t*)a,
+                               (const bf16_t*)b, (bf16_t*)y, n);
+        } else {
+            int blocks = (int)std::min<long long>((n + threads - 1) / threads, 4096);
+            hipLaunchKernelGGL((add_kernel<bf16_t, 1>), dim3(blocks), dim3(threads), 0, s, (const bf16_t*)a,
+                               (const bf16_t*)b, (bf16_t*)y, n);
+        }
+    }
+    VITMI_LAUNCH_CHECK("vitmi_add");
+    return VITMI_OK;
+}
+
+extern "C" long long vitmi_colsum_workspace_bytes(long long rows, int cols) {
+    return (long long)colsum_chunks(rows) * cols * (long long)sizeof(float);
+}
+
+extern "C" int vitmi_colsum(const void* x, int dt, long long rows, int cols, long long ld, float* out, void* workspace,
+                            void* stream) {
+    VITMI_CHECK_ARG(x && out && workspace, "vitmi_colsum: null pointer");
+    VITMI_CHECK_ARG(rows > 0 && cols > 0 && ld >= cols, "vitmi_colsum: bad shape rows=%lld cols=%d ld=%lld", rows, cols,
+                    ld);
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_OTHER, s, (double)rows * cols * (dt == VITMI_F32 ? 4 : 2));
+    if (dt == VITMI_F32) return launch_colsum<float>(x, rows, cols, ld, out, workspace, s);
+    if (dt == VITMI_BF16) return launch_colsum<bf16_t>(x, rows, cols, ld, out, workspace, s);
+    vitmi_set_error("vitmi_colsum: bad dtype %d", dt);
+    return VITMI_ERR_BAD_ARG;
+}
+
+extern "C" int vitmi_tokens_assemble_fwd(const void* patch, const float* cls, const float* pe,
+                                         const long long* seq_ord, void* out, int dt, int B, int N, int D,
+                                         void* stream) {
+    VITMI_CHECK_ARG(patch && cls && out, "vitmi_tokens_assemble_fwd: null pointer");
+    VITMI_CHECK_ARG(B > 0 && N > 1 && D > 0, "vitmi_tokens_assemble_fwd: bad shape B=%d N=%d D=%d", B, N, D);
+    hipStream_t s = as_stream(stream);
+    const int esz = dt == VITMI_F32 ? 4 : 2;
+    // algorithmic bytes: read the patch rows, write the token rows, read the table rows and the indices once
+    ProfScope prof(VITMI_FAM_TOKENS, s,
+                   (double)B * (N - 1) * D * esz + (double)B * N * D * esz + (double)N * D * 4 + 8.0 * N);
+    const long long rows = (long long)B * N;
+    const bool vec = (D % 4 == 0) && aligned_to(patch, 16) && aligned_to(out, 16) && aligned_to(cls, 16) &&
+                     (!pe || aligned_to(pe, 16));
+    dim3 grid(ceil_div(rows, 4)), block(256);
+    if (dt == VITMI_F32) {
+        if (vec)
+            hipLaunchKernelGGL((tokens_assemble_fwd_kernel<float, 4>), grid, block, 0, s, (const float*)patch, cls, pe,
+                               seq_ord, (float*)out, B, N, D);
+        else
+            hipLaunchKernelGGL((tokens_assemble_fwd_kernel<float, 1>), grid, block, 0, s, (const float*)patch, cls, pe,
+                               seq_ord, (float*)out, B, N, D);
+    } else if (dt == VITMI_BF16) {
+        if (vec)
+            hipLaunchKernelGGL((tokens_assemble_fwd_kernel<bf16_t, 4>), grid, block, 0, s, (const bf16_t*)patch, cls,
+                               pe, seq_ord, (bf16_t*)out, B, N, D);
+        else
+            hipLaunchKernelGGL((tokens_assemble_fwd_kernel<bf16_t, 1>), grid, block, 0, s, (const bf16_t*)patch, cls,
+                               pe, seq_ord, (bf16_t*)out, B, N, D);
+    } else {
+        vitmi_set_error("vitmi_tokens_assemble_fwd: bad dtype %d", dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    VITMI_LAUNCH_CHECK("vitmi_tokens_assemble_fwd");
+    return VITMI_OK;
+}
+
+extern "C" long long vitmi_tokens_assemble_bwd_workspace_bytes(int N, int D) {
+    // position sums [N*D] followed by the column-sum partials (at most 128 chunks of N*D floats)
+    return ((long long)N * D + 128ll * N * D) * (long long)sizeof(float);
+}
+
+extern "C" int vitmi_tokens_assemble_bwd(const void* dx, const long long* seq_ord, float* dcls, float* dpe,
+                                         int pe_rows, void* workspace, int dt, int B, int N, int D, void* stream) {
+    VITMI_CHECK_ARG(dx && dcls && workspace, "vitmi_tokens_assemble_bwd: null pointer");
+    VITMI_CHECK_ARG(B > 0 && N > 1 && D > 0 && pe_rows >= 0, "vitmi_tokens_assemble_bwd: bad shape");
+    hipStream_t s = as_stream(stream);
+    const int esz = dt == VITMI_F32 ? 4 : 2;
+    ProfScope prof(VITMI_FAM_TOKENS, s, (double)B * N * D * esz + (double)(pe_rows + 1) * D * 4);
+    float* possum = (float*)workspace;
+    float* partial = possum + (long long)N * D;
+    // sum over the batch: a column sum of the [B, N*D] view
+    int rc;
+    if (dt == VITMI_F32)
+        rc = launch_colsum<float>(dx, B, N * D, (long long)N * D, possum, partial, s);
+    else if (dt == VITMI_BF16)
+        rc = launch_colsum<bf16_t>(dx, B, N * D, (long long)N * D, possum, partial, s);
+    else {
+        vitmi_set_error("vitmi_tokens_assemble_bwd: bad dtype %d", dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL(tokens_scatter_rows_kernel, dim3(pe_rows + 1), dim3(256), 0, s, possum, seq_ord, dcls, dpe,
+                       pe_rows, N, D);
+    VITMI_LAUNCH_CHECK("vitmi_tokens_assemble_bwd");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_layernorm_fwd(const void* x, long long ldx, const float* gamma, const float* beta, void* y,
+                                   float* mean, float* rstd, int dt, long long rows, int D, float eps, void* stream) {
+    VITMI_CHECK_ARG(x && gamma && beta && y, "vitmi_layernorm_fwd: null pointer");
+    VITMI_CHECK_ARG(rows > 0 && D > 0 && ldx >= D, "vitmi_layernorm_fwd: bad shape rows=%lld D=%d ldx=%lld", rows, D,
+                    ldx);
+    hipStream_t s = as_stream(stream);
+    const int esz = dt == VITMI_F32 ? 4 : 2;
+    ProfScope prof(VITMI_FAM_LAYERNORM, s, 2.0 * rows * D * esz);
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && aligned_to(x, 16) && aligned_to(y, 16) &&
+                     aligned_to(gamma, 16) && aligned_to(beta, 16);
+    const int iters = ceil_div(D, 64 * (vec ? 4 : 1));
+    if (iters > 8) {
+        vitmi_set_error("vitmi_layernorm_fwd: D=%d exceeds the supported row length %d", D, 64 * 8 * (vec ? 4 : 1));
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    if (dt != VITMI_F32 && dt != VITMI_BF16) {
+        vitmi_set_error("vitmi_layernorm_fwd: bad dtype %d", dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    dim3 grid(ceil_div(rows, 4)), block(256);
+#define LN_FWD(T, V, I)                                                                                         \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, I>), grid, block, 0, s, (const T*)x, ldx, gamma, beta, (T*)y, \
+                       mean, rstd, rows, D, eps)
+#define LN_FWD_I(T, V)                         \
+    do {                                       \
+        if (iters <= 1) LN_FWD(T, V, 1);       \
+        else if (iters == 2) LN_FWD(T, V, 2);  \
+        else if (iters == 3) LN_FWD(T, V, 3);  \
+        else if (iters == 4) LN_FWD(T, V, 4);  \
+        else if (iters <= 6) LN_FWD(T, V, 6);  \
+        else LN_FWD(T, V, 8);                  \
+    } while (0)
+    if (dt == VITMI_F32) {
+        if (vec) LN_FWD_I(float, 4); else LN_FWD_I(float, 1);
+    } else {
+        if (vec) LN_FWD_I(bf16_t, 4); else LN_FWD_I(bf16_t, 1);
+    }
+#undef LN_FWD_I
+#undef LN_FWD
+    VITMI_LAUNCH_CHECK("vitmi_layernorm_fwd");
+    return VITMI_OK;
+}
+
+extern "C" long long vitmi_layernorm_bwd_workspace_bytes(long long rows, int D) {
+    return (long long)ln_bwd_blocks(rows) * 2 * D * (long long)sizeof(float);
+}
+
+extern "C" int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx, const float* gamma, const float* mean,
+                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                   void* workspace, int dt, long long rows, int D, void* stream) {
+    VITMI_CHECK_ARG(dy && x && gamma && mean && rstd && dx && workspace, "vitmi_layernorm_bwd: null pointer");
+    VITMI_CHECK_ARG(rows > 0 && D > 0 && ldx >= D, "vitmi_layernorm_bwd: bad shape");
+    hipStream_t s = as_stream(stream);
+    const int esz = dt == VITMI_F32 ? 4 : 2;
+    ProfScope prof(VITMI_FAM_LAYERNORM, s, (dres ? 4.0 : 3.0) * rows * D * esz);
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && aligned_to(x, 16) && aligned_to(dy, 16) && aligned_to(dx, 16) &&
+                     aligned_to(gamma, 16) && (!dres || aligned_to(dres, 16));
+    const int iters = ceil_div(D, 64 * (vec ? 4 : 1));
+    if (iters > 8) {
+        vitmi_set_error("vitmi_layernorm_bwd: D=%d exceeds the supported row length %d", D, 64 * 8 * (vec ? 4 : 1));
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    if (dt != VITMI_F32 && dt != VITMI_BF16) {
+        vitmi_set_error("vitmi_layernorm_bwd: bad dtype %d", dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    const int blocks = ln_bwd_blocks(rows);
+    float* partial = (float*)workspace;
+    dim3 grid(blocks), block(256);
+#define LN_BWD(T, V, I)                                                                                        \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, I>), grid, block, 0, s, (const T*)dy, (const T*)x, ldx, gamma, \
+                       mean, rstd, (const T*)dres, (T*)dx, partial, rows, D)
+#define LN_BWD_I(T, V)                         \
+    do {                                       \
+        if (iters <= 1) LN_BWD(T, V, 1);       \
+        else if (iters == 2) LN_BWD(T, V, 2);  \
+        else if (iters == 3) LN_BWD(T, V, 3);  \
+        else if (iters == 4) LN_BWD(T, V, 4);  \
+        else if (iters <= 6) LN_BWD(T, V, 6);  \
+        else LN_BWD(T, V, 8);                  \
+    } while (0)
+    if (dt == VITMI_F32) {
+        if (vec) LN_BWD_I(float, 4); else LN_BWD_I(float, 1);
+    } else {
+        if (vec) LN_BWD_I(bf16_t, 4); else LN_BWD_I(bf16_t, 1);
+    }
+#undef LN_BWD_I
+#undef LN_BWD
+    VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd");
+    if (dgamma || dbeta) {
+        hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, s, partial, blocks, D,
+                           dgamma, dbeta);
+        VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd(final)");
+    }
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_meanpool_fwd(const void* x, void* out, int dt, int B, int N, int D, void* stream) {
+    VITMI_CHECK_ARG(x && out && B > 0 && N > 0 && D > 0, "vitmi_meanpool_fwd: bad argument");
+    hipStream_t s = as_stream(stream);
+    dim3 grid(ceil_div((long long)B * D, 256)), block(256);
+    if (dt == VITMI_F32)
+        hipLaunchKernelGGL(meanpool_fwd_kernel<float>, grid, block, 0, s, (const float*)x, (float*)out, B, N, D);
+    else if (dt == VITMI_BF16)
+        hipLaunchKernelGGL(meanpool_fwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, (bf16_t*)out, B, N, D);
+    else {
+        vitmi_set_error("vitmi_meanpool_fwd: bad dtype %d", dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    VITMI_LAUNCH_CHECK("vitmi_meanpool_fwd");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_meanpool_bwd(const void* dout, void* dx, int dt, int B, int N, int D, void* stream) {
+    VITMI_CHECK_ARG(dout && dx && B > 0 && N > 0 && D > 0, "vitmi_meanpool_bwd: bad argument");
+    hipStream_t s = as_stream(stream);
+    dim3 grid(ceil_div((long long)B * N * D, 256)), block(256);
+    if (dt == VITMI_F32)
+        hipLaunchKernelGGL(meanpool_bwd_kernel<float>, grid, block, 0, s, (const float*)dout, (float*)dx, B, N, D);
+    else if (dt == VITMI_BF16)
+        hipLaunchKernelGGL(meanpool_bwd_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)dout, (bf16_t*)dx, B, N, D);
+    else {
+        vitmi_set_error("vitmi_meanpool_bwd: bad dtype %d", dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    VITMI_LAUNCH_CHECK("vitmi_meanpool_bwd");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_bf16,
+                               long long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                               int step, float grad_scale, void* stream) {
+    VITMI_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "vitmi_adam_step: bad argument");
+    if (n == 0) return VITMI_OK;
+    hipStream_t s = as_stream(stream);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
+                       (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+    VITMI_LAUNCH_CHECK("vitmi_adam_step");
+    return VITMI_OK;
+}

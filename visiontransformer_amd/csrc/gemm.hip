@@ -1,0 +1,458 @@
+// GEMM kernels of the ViT encoder path.
+//
+//   C(m,n) = sum_k A(m,k) * B(n,k)   [+ bias[n]] [GELU / dGELU] [+ residual(m,n)]
+//
+// bf16: 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile as 4x4
+//       v_mfma_f32_16x16x32_bf16 accumulators; operands are staged global -> VGPR -> LDS with
+//       the next tile's global loads in flight under the current tile's MFMAs; the LDS image is
+//       always [row][k] with a 16-byte row pad (144-B rows: conflict-free ds_read_b128), whatever
+//       the operand's memory layout (an operand that is contiguous along its row index is
+//       transposed on its way into LDS).
+// fp32: 64x64x16 VALU tile kernel with the same epilogue (exact fp32 FMA; parity path).
+//
+// The patch-embedding GEMMs reuse the bf16/fp32 cores with a loader that gathers patch
+// elements straight from the NCHW image (no im2col buffer).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDS_LD = BK + 8;  // elements per LDS row (144 B)
+constexpr int NTHREADS = 256;
+constexpr int CHUNKS = (BM * BK / 8) / NTHREADS;  // 16-byte chunks per thread per operand tile = 4
+
+struct Epilogue {
+    void* C;
+    long long ldc;
+    const float* bias;
+    const void* res;
+    long long ldr;
+    void* aux;
+    long long ldaux;
+    // patch-embedding forward writes token j of image b at C + b*batch_stride + j*ldc
+    int tokens_per_image;  // 0 = plain row-major
+    long long batch_stride;
+};
+
+template <int EPI, typename T, typename OutT>
+__device__ __forceinline__ void epilogue_store(const Epilogue& e, int m, int n, float v) {
+    if (e.bias) v += e.bias[n];
+    if (EPI == VITMI_EPI_GELU) {
+        if (e.aux) reinterpret_cast<T*>(e.aux)[(long long)m * e.ldaux + n] = from_f32<T>(v);
+        v = gelu_erf(v);
+    } else if (EPI == VITMI_EPI_DGELU) {
+        v *= gelu_erf_grad(to_f32(reinterpret_cast<const T*>(e.aux)[(long long)m * e.ldaux + n]));
+    }
+    if (e.res) v += to_f32(reinterpret_cast<const T*>(e.res)[(long long)m * e.ldr + n]);
+    long long off;
+    if (e.tokens_per_image > 0) {
+        const int b = m / e.tokens_per_image, j = m - b * e.tokens_per_image;
+        off = (long long)b * e.batch_stride + (long long)j * e.ldc + n;
+    } else {
+        off = (long long)m * e.ldc + n;
+    }
+    reinterpret_cast<OutT*>(e.C)[off] = from_f32<OutT>(v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Operand loaders.  A tile is ROWS(=128) x BK(=64) bf16 in LDS, [row][k].  Every thread owns 4
+// 16-byte chunks.  KC: a chunk is 8 consecutive k of one row.  MC: a chunk is 8 consecutive rows
+// at one k (the operand is contiguous along its row index) and is scattered into LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
+    return z;
+}
+
+template <bool KC>
+struct StridedLoader {
+    const bf16_t* p;
+    long long s_r, s_k;  // element strides along the row index and along k
+    int R, K;            // bounds
+    int vec;             // 16-byte loads allowed (alignment checked on the host)
+
+    __device__ __forceinline__ void load(int r0, int k0, bf16x8 (&v)[CHUNKS]) const {
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int c = threadIdx.x + i * NTHREADS;
+            if (KC) {
+                const int r = r0 + (c >> 3), k = k0 + (c & 7) * 8;
+                if (r < R && k + 8 <= K && vec) {
+                    v[i] = *reinterpret_cast<const bf16x8*>(p + (long long)r * s_r + k);
+                } else {
+                    bf16x8 t = zero8();
+                    if (r < R) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (k + j < K) t[j] = p[(long long)r * s_r + (long long)(k + j) * s_k];
+                    }
+                    v[i] = t;
+                }
+            } else {
+                const int k = k0 + (c >> 4), r = r0 + (c & 15) * 8;
+                if (k < K && r + 8 <= R && vec) {
+                    v[i] = *reinterpret_cast<const bf16x8*>(p + (long long)k * s_k + r);
+                } else {
+                    bf16x8 t = zero8();
+                    if (k < K) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            if (r + j < R) t[j] = p[(long long)(r + j) * s_r + (long long)k * s_k];
+                    }
+                    v[i] = t;
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ static void store(bf16_t* lds, const bf16x8 (&v)[CHUNKS]) {
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int c = threadIdx.x + i * NTHREADS;
+            if (KC) {
+                *reinterpret_cast<bf16x8*>(lds + (c >> 3) * LDS_LD + (c & 7) * 8) = v[i];
+            } else {
+                const int k = c >> 4, r = (c & 15) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) lds[(r + j) * LDS_LD + k] = v[i][j];
+            }
+        }
+    }
+};
+
+// Patch operand: logical matrix P[token m][element e], m = (b, gy, gx), e = (c, i, j),
+// P = x[b, c, gy*ps + i, gx*ps + j].  TOKEN_ROWS: tile rows are tokens and k runs over patch
+// elements (forward).  !TOKEN_ROWS: tile rows are patch elements and k runs over tokens
+// (weight gradient); chunks still run along e, so they are scattered into LDS.
+template <typename XT, bool TOKEN_ROWS>
+struct PatchLoader {
+    const XT* x;
+    int C, H, W, ps, gw, gh;
+    int tokens, elems;  // B*gh*gw, C*ps*ps
+
+    __device__ __forceinline__ long long addr(int m, int e) const {
+        const int per = gh * gw;
+        const int b = m / per, t = m - b * per;
+        const int gy = t / gw, gx = t - gy * gw;
+        const int c = e / (ps * ps), q = e - c * ps * ps;
+        const int i = q / ps, j = q - i * ps;
+        return (((long long)b * C + c) * H + (gy * ps + i)) * W + gx * ps + j;
+    }
+    __device__ __forceinline__ bf16x8 chunk(int m, int e0) const {
+        bf16x8 t = zero8();
+        if (m >= tokens) return t;
+        if ((ps & 7) == 0 && e0 + 8 <= elems) {
+            // 8 elements of one patch row: contiguous in the image
+            const XT* src = x + addr(m, e0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = (bf16_t)to_f32(src[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (e0 + j < elems) t[j] = (bf16_t)to_f32(x[addr(m, e0 + j)]);
+        }
+        return t;
+    }
+    __device__ __forceinline__ void load(int r0, int k0, bf16x8 (&v)[CHUNKS]) const {
+#pragma unroll
+        for (int i = 0; i < CHUNKS; ++i) {
+            const int c = threadIdx.x + i * NTHREADS;
+            if (TOKEN_ROWS)
+                v[i] = chunk(r0 + (c >> 3), k0 + (c & 7) * 8);
+            else
+                v[i] = chunk(k0 + (c >> 4), r0 + (c & 15) * 8);
+        }
+    }
+    __device__ __forceinline__ static void store(bf16_t* lds, const bf16x8 (&v)[CHUNKS]) {
+        StridedLoader<TOKEN_ROWS>::store(lds, v);
+    }
+};
+
+template <int EPI, typename OutT, class LoaderA, class LoaderB>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(LoaderA la, LoaderB lb, Epilogue epi, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) bf16_t As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[BN * LDS_LD];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 ra[CHUNKS], rb[CHUNKS];
+    la.load(m0, 0, ra);
+    lb.load(n0, 0, rb);
+    const int nk = (K + BK - 1) / BK;
+    for (int kt = 0; kt < nk; ++kt) {
+        LoaderA::store(As, ra);
+        LoaderB::store(Bs, rb);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            la.load(m0, (kt + 1) * BK, ra);
+            lb.load(n0, (kt + 1) * BK, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 16 + fr) * LDS_LD + ks * 32 + fg * 8]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 64 + j * 16 + fr) * LDS_LD + ks * 32 + fg * 8]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // accumulator element r of tile (i,j): row = 4*fg + r, col = fr
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm * 64 + i * 16 + fg * 4 + r;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + fr;
+                if (n < N) epilogue_store<EPI, bf16_t, OutT>(epi, m, n, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 path: 64x64x16 tiles, 256 threads, 4x4 outputs per thread, generic strides.
+// ------------------------------------------------------------------------------------------------
+struct F32Operand {
+    const float* p;
+    long long s_r, s_k;
+    int R;
+    // patch gather (s_r/s_k unused when patch != 0)
+    int patch, token_rows, C, H, W, ps, gw, gh;
+    __device__ __forceinline__ float at(int r, int k, int K) const {
+        if (r >= R || k >= K) return 0.f;
+        if (!patch) return p[(long long)r * s_r + (long long)k * s_k];
+        const int m = token_rows ? r : k, e = token_rows ? k : r;
+        const int per = gh * gw;
+        const int b = m / per, t = m - b * per;
+        const int gy = t / gw, gx = t - gy * gw;
+        const int c = e / (ps * ps), q = e - c * ps * ps;
+        const int i = q / ps, j = q - i * ps;
+        return p[(((long long)b * C + c) * H + (gy * ps + i)) * W + gx * ps + j];
+    }
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand B, Epilogue epi, int M, int N, int K) {
+    constexpr int TM = 64, TN = 64, TK = 16;
+    __shared__ float As[TK][TM + 4];
+    __shared__ float Bs[TK][TN + 4];
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const bool a_kc = A.patch ? (A.token_rows != 0) : (A.s_k == 1);
+    const bool b_kc = B.patch ? (B.token_rows != 0) : (B.s_k == 1);
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += TK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = threadIdx.x + i * 256;
+            int r, k;
+            if (a_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
+            As[k][r] = A.at(m0 + r, k0 + k, K);
+            if (b_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
+            Bs[k][r] = B.at(n0 + r, k0 + k, K);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TK; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n < N) epilogue_store<EPI, float, float>(epi, m, n, acc[i][j]);
+        }
+    }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+template <int EPI, typename OutT, class LA, class LB>
+void launch_bf16(const LA& la, const LB& lb, const Epilogue& epi, int M, int N, int K, hipStream_t s) {
+    dim3 grid(ceil_div(N, BN), ceil_div(M, BM));
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, OutT, LA, LB>), grid, dim3(NTHREADS), 0, s, la, lb, epi, M, N, K);
+}
+
+template <int EPI, typename OutT>
+void dispatch_bf16_layout(bool a_kc, bool b_kc, const void* A, long long sam, long long sak, const void* B,
+                          long long sbn, long long sbk, const Epilogue& epi, int M, int N, int K, hipStream_t s) {
+    const bf16_t* a = (const bf16_t*)A;
+    const bf16_t* b = (const bf16_t*)B;
+    // 16-byte loads need the contiguous direction to be the chunk direction and every chunk start aligned
+    const int va = al16(A) && (a_kc ? (sak == 1 && sam % 8 == 0) : (sam == 1 && sak % 8 == 0));
+    const int vb = al16(B) && (b_kc ? (sbk == 1 && sbn % 8 == 0) : (sbn == 1 && sbk % 8 == 0));
+    if (a_kc && b_kc)
+        launch_bf16<EPI, OutT>(StridedLoader<true>{a, sam, sak, M, K, va}, StridedLoader<true>{b, sbn, sbk, N, K, vb},
+                               epi, M, N, K, s);
+    else if (a_kc && !b_kc)
+        launch_bf16<EPI, OutT>(StridedLoader<true>{a, sam, sak, M, K, va}, StridedLoader<false>{b, sbn, sbk, N, K, vb},
+                               epi, M, N, K, s);
+    else if (!a_kc && b_kc)
+        launch_bf16<EPI, OutT>(StridedLoader<false>{a, sam, sak, M, K, va}, StridedLoader<true>{b, sbn, sbk, N, K, vb},
+                               epi, M, N, K, s);
+    else
+        launch_bf16<EPI, OutT>(StridedLoader<false>{a, sam, sak, M, K, va},
+                               StridedLoader<false>{b, sbn, sbk, N, K, vb}, epi, M, N, K, s);
+}
+
+}  // namespace
+
+extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long sam, long long sak, const void* B,
+                          long long sbn, long long sbk, void* C, long long ldc, int c_dt, int epilogue,
+                          const float* bias, const void* residual, long long ldr, void* aux, long long ldaux,
+                          void* stream) {
+    VITMI_CHECK_ARG(A && B && C, "vitmi_gemm: null operand");
+    VITMI_CHECK_ARG(M > 0 && N > 0 && K > 0, "vitmi_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    VITMI_CHECK_ARG(ldc >= N, "vitmi_gemm: ldc=%lld < N=%d", ldc, N);
+    VITMI_CHECK_ARG(epilogue >= VITMI_EPI_NONE && epilogue <= VITMI_EPI_DGELU, "vitmi_gemm: bad epilogue %d", epilogue);
+    VITMI_CHECK_ARG(epilogue != VITMI_EPI_DGELU || aux, "vitmi_gemm: dGELU epilogue needs aux");
+    VITMI_CHECK_ARG(!residual || ldr >= N, "vitmi_gemm: ldr=%lld < N=%d", ldr, N);
+    VITMI_CHECK_ARG(!aux || ldaux >= N, "vitmi_gemm: ldaux=%lld < N=%d", ldaux, N);
+    VITMI_CHECK_ARG(sam > 0 && sak > 0 && sbn > 0 && sbk > 0, "vitmi_gemm: strides must be positive");
+    hipStream_t s = as_stream(stream);
+    Epilogue epi{C, ldc, bias, residual, ldr, aux, ldaux, 0, 0};
+    ProfScope prof(VITMI_FAM_GEMM, s, 2.0 * M * N * K);
+    if (dt == VITMI_F32) {
+        VITMI_CHECK_ARG(c_dt == VITMI_F32, "vitmi_gemm: fp32 compute writes fp32 output");
+        F32Operand a{(const float*)A, sam, sak, M, 0, 0, 0, 0, 0, 0, 0, 0};
+        F32Operand b{(const float*)B, sbn, sbk, N, 0, 0, 0, 0, 0, 0, 0, 0};
+        dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+        if (epilogue == VITMI_EPI_NONE)
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+        else if (epilogue == VITMI_EPI_GELU)
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+        else
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_DGELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+        VITMI_LAUNCH_CHECK("vitmi_gemm(f32)");
+        return VITMI_OK;
+    }
+    VITMI_CHECK_ARG(dt == VITMI_BF16, "vitmi_gemm: bad dtype %d", dt);
+    VITMI_CHECK_ARG(c_dt == VITMI_BF16 || (c_dt == VITMI_F32 && epilogue == VITMI_EPI_NONE),
+                    "vitmi_gemm: fp32 output supports only the plain epilogue");
+    // an operand is K-contiguous unless its row stride is 1 and its k stride is not
+    const bool a_kc = !(sam == 1 && sak != 1);
+    const bool b_kc = !(sbn == 1 && sbk != 1);
+    if (c_dt == VITMI_F32)
+        dispatch_bf16_layout<VITMI_EPI_NONE, float>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
+    else if (epilogue == VITMI_EPI_NONE)
+        dispatch_bf16_layout<VITMI_EPI_NONE, bf16_t>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
+    else if (epilogue == VITMI_EPI_GELU)
+        dispatch_bf16_layout<VITMI_EPI_GELU, bf16_t>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
+    else
+        dispatch_bf16_layout<VITMI_EPI_DGELU, bf16_t>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
+    VITMI_LAUNCH_CHECK("vitmi_gemm(bf16)");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, const float* bias, void* out, int dt,
+                                     int B, int C, int H, int W, int p, int D, long long out_batch_stride,
+                                     void* stream) {
+    VITMI_CHECK_ARG(x && w && out, "vitmi_patch_embed_fwd: null pointer");
+    VITMI_CHECK_ARG(B > 0 && C > 0 && p > 0 && D > 0 && H > 0 && W > 0 && H % p == 0 && W % p == 0,
+                    "vitmi_patch_embed_fwd: bad geometry B=%d C=%d H=%d W=%d p=%d D=%d", B, C, H, W, p, D);
+    const int gh = H / p, gw = W / p, per = gh * gw;
+    const int M = B * per, K = C * p * p, N = D;
+    VITMI_CHECK_ARG(out_batch_stride >= (long long)per * D, "vitmi_patch_embed_fwd: out_batch_stride too small");
+    hipStream_t s = as_stream(stream);
+    Epilogue epi{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride};
+    ProfScope prof(VITMI_FAM_GEMM, s, 2.0 * M * N * K);
+    if (dt == VITMI_F32) {
+        VITMI_CHECK_ARG(x_dt == VITMI_F32, "vitmi_patch_embed_fwd: fp32 compute needs an fp32 image");
+        F32Operand a{(const float*)x, 0, 0, M, 1, 1, C, H, W, p, gw, gh};
+        F32Operand b{(const float*)w, K, 1, N, 0, 0, 0, 0, 0, 0, 0, 0};
+        dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+        VITMI_LAUNCH_CHECK("vitmi_patch_embed_fwd(f32)");
+        return VITMI_OK;
+    }
+    VITMI_CHECK_ARG(dt == VITMI_BF16, "vitmi_patch_embed_fwd: bad dtype %d", dt);
+    StridedLoader<true> lb{(const bf16_t*)w, K, 1, N, K, al16(w) && K % 8 == 0};
+    if (x_dt == VITMI_F32) {
+        PatchLoader<float, true> la{(const float*)x, C, H, W, p, gw, gh, M, K};
+        launch_bf16<VITMI_EPI_NONE, bf16_t>(la, lb, epi, M, N, K, s);
+    } else if (x_dt == VITMI_BF16) {
+        PatchLoader<bf16_t, true> la{(const bf16_t*)x, C, H, W, p, gw, gh, M, K};
+        launch_bf16<VITMI_EPI_NONE, bf16_t>(la, lb, epi, M, N, K, s);
+    } else {
+        vitmi_set_error("vitmi_patch_embed_fwd: bad image dtype %d", x_dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    VITMI_LAUNCH_CHECK("vitmi_patch_embed_fwd(bf16)");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, long long dy_batch_stride, float* dw,
+                                       int dt, int B, int C, int H, int W, int p, int D, void* stream) {
+    VITMI_CHECK_ARG(x && dy && dw, "vitmi_patch_embed_bwd_w: null pointer");
+    VITMI_CHECK_ARG(B > 0 && C > 0 && p > 0 && D > 0 && H > 0 && W > 0 && H % p == 0 && W % p == 0,
+                    "vitmi_patch_embed_bwd_w: bad geometry");
+    const int gh = H / p, gw = W / p, per = gh * gw;
+    const int T = B * per, E = C * p * p;
+    VITMI_CHECK_ARG(dy_batch_stride == (long long)per * D,
+                    "vitmi_patch_embed_bwd_w: dy must be dense [B, tokens, D] (batch stride %lld != %lld)",
+                    dy_batch_stride, (long long)per * D);
+    hipStream_t s = as_stream(stream);
+    // dW[d, e] = sum_t dy[t, d] * P[t, e]:  rows of A = d (dy is contiguous along d), rows of B = e, k = t
+    Epilogue epi{dw, E, nullptr, nullptr, 0, nullptr, 0, 0, 0};
+    ProfScope prof(VITMI_FAM_GEMM, s, 2.0 * D * E * (double)T);
+    if (dt == VITMI_F32) {
+        VITMI_CHECK_ARG(x_dt == VITMI_F32, "vitmi_patch_embed_bwd_w: fp32 compute needs an fp32 image");
+        F32Operand a{(const float*)dy, 1, D, D, 0, 0, 0, 0, 0, 0, 0, 0};
+        F32Operand b{(const float*)x, 0, 0, E, 1, 0, C, H, W, p, gw, gh};
+        dim3 grid(ceil_div(E, 64), ceil_div(D, 64));
+        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, D, E, T);
+        VITMI_LAUNCH_CHECK("vitmi_patch_embed_bwd_w(f32)");
+        return VITMI_OK;
+    }
+    VITMI_CHECK_ARG(dt == VITMI_BF16, "vitmi_patch_embed_bwd_w: bad dtype %d", dt);
+    StridedLoader<false> la{(const bf16_t*)dy, 1, D, D, T, al16(dy) && D % 8 == 0};
+    if (x_dt == VITMI_F32) {
+        PatchLoader<float, false> lb{(const float*)x, C, H, W, p, gw, gh, T, E};
+        launch_bf16<VITMI_EPI_NONE, float>(la, lb, epi, D, E, T, s);
+    } else if (x_dt == VITMI_BF16) {
+        PatchLoader<bf16_t, false> lb{(const bf16_t*)x, C, H, W, p, gw, gh, T, E};
+        launch_bf16<VITMI_EPI_NONE, float>(la, lb, epi, D, E, T, s);
+    } else {
+        vitmi_set_error("vitmi_patch_embed_bwd_w: bad image dtype %d", x_dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    VITMI_LAUNCH_CHECK("vitmi_patch_embed_bwd_w(bf16)");
+    return VITMI_OK;
+}

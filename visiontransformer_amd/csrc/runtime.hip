@@ -1,0 +1,108 @@
+// Error reporting and per-family launch timers of libvitmi_hip.so.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void vitmi_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int vitmi_hip_fail(hipError_t e, const char* what) {
+    vitmi_set_error("%s: %s", what, hipGetErrorString(e));
+    return VITMI_ERR_HIP;
+}
+
+extern "C" int vitmi_version(void) { return VITMI_VERSION; }
+extern "C" const char* vitmi_last_error(void) { return g_err; }
+
+// ---- launch timers ----------------------------------------------------------------------------
+// Events are created on the device that is current at record time and are only ever read
+// through vitmi_prof_read, which synchronises them.  Disabled by default: zero cost.
+namespace {
+struct Pair {
+    hipEvent_t a, b;
+    double work;
+};
+struct Family {
+    std::vector<Pair> pairs;
+    hipEvent_t pending = nullptr;
+    double pending_work = 0;
+};
+std::mutex g_mu;
+bool g_on = false;
+Family g_fam[VITMI_FAM_COUNT];
+}  // namespace
+
+void vitmi_prof_record_begin(int family, hipStream_t s, double work) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Family& f = g_fam[family];
+    hipEvent_t a;
+    if (hipEventCreate(&a) != hipSuccess) return;
+    (void)hipEventRecord(a, s);
+    f.pending = a;
+    f.pending_work = work;
+}
+
+void vitmi_prof_record_end(int family, hipStream_t s) {
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Family& f = g_fam[family];
+    if (!f.pending) return;
+    hipEvent_t b;
+    if (hipEventCreate(&b) != hipSuccess) return;
+    (void)hipEventRecord(b, s);
+    f.pairs.push_back({f.pending, b, f.pending_work});
+    f.pending = nullptr;
+}
+
+extern "C" int vitmi_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& f : g_fam) {
+        for (auto& p : f.pairs) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+        f.pairs.clear();
+        if (f.pending) (void)hipEventDestroy(f.pending);
+        f.pending = nullptr;
+    }
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_prof_read(int family, double* total_ms, double* total_work, long long* launches) {
+    VITMI_CHECK_ARG(family >= 0 && family < VITMI_FAM_COUNT, "vitmi_prof_read: family %d out of range", family);
+    std::lock_guard<std::mutex> lk(g_mu);
+    double ms = 0, work = 0;
+    long long n = 0;
+    for (auto& p : g_fam[family].pairs) {
+        hipError_t e = hipEventSynchronize(p.b);
+        if (e != hipSuccess) return vitmi_hip_fail(e, "vitmi_prof_read: hipEventSynchronize");
+        float t = 0;
+        e = hipEventElapsedTime(&t, p.a, p.b);
+        if (e != hipSuccess) return vitmi_hip_fail(e, "vitmi_prof_read: hipEventElapsedTime");
+        ms += t;
+        work += p.work;
+        ++n;
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = work;
+    if (launches) *launches = n;
+    return VITMI_OK;
+}

@@ -1,0 +1,462 @@
+"""torch.autograd glue over the C ABI of libvitmi_hip.so.
+
+Every function here moves raw device pointers, shapes and the current HIP stream across the
+boundary; tensors are allocated by PyTorch's caching allocator.  There is no CPU or eager
+fallback: CPU tensors raise.
+"""
+import torch
+
+from . import _lib
+from ._lib import BF16, EPI_DGELU, EPI_GELU, EPI_NONE, F32, check, lib
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise TypeError(f"visiontransformer_amd computes in float32 or bfloat16, not {t.dtype}") from None
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "visiontransformer_amd runs only on ROCm device tensors (HIP kernels for gfx950); "
+                "got a CPU tensor and there is no CPU fallback")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------------------------------------
+# compute-dtype copies of fp32 parameters, refreshed when the parameter's version changes
+# ---------------------------------------------------------------------------------------------
+_cast_cache = {}
+
+
+def cast(t, dtype):
+    """t converted to `dtype` by the HIP cast kernel (t itself when it already matches)."""
+    if t.dtype == dtype:
+        return t
+    _need_gpu(t)
+    src = t.detach().contiguous()
+    out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(lib.vitmi_cast(_p(src), _dt(src), _p(out), _dt(dtype), src.numel(), _stream()), "vitmi_cast")
+    return out
+
+
+def compute_copy(param, dtype):
+    """A `dtype` copy of parameter `param`, cached until the parameter is next modified in place."""
+    if param.dtype == dtype:
+        return param.detach()
+    key = (id(param), dtype)
+    hit = _cast_cache.get(key)
+    ver = param._version
+    if hit is not None and hit[0] == ver and hit[1] == param.data_ptr() and hit[2].device == param.device:
+        return hit[2]
+    c = cast(param, dtype)
+    _cast_cache[key] = (ver, param.data_ptr(), c)
+    return c
+
+
+def clear_cast_cache():
+    _cast_cache.clear()
+
+
+# ---------------------------------------------------------------------------------------------
+# thin wrappers (no autograd)
+# ---------------------------------------------------------------------------------------------
+def gemm_raw(dt, M, N, K, A, sam, sak, B, sbn, sbk, C, ldc, c_dt, epi=EPI_NONE, bias=None, res=None, ldr=0,
+             aux=None, ldaux=0):
+    check(lib.vitmi_gemm(dt, M, N, K, _p(A), sam, sak, _p(B), sbn, sbk, _p(C), ldc, c_dt, epi, _p(bias), _p(res), ldr,
+                         _p(aux), ldaux, _stream()), "vitmi_gemm")
+
+
+def linear_fwd(x2, w, bias=None, res=None, epi=EPI_NONE, want_aux=False, out_dtype=None):
+    """y[T,N] = x2[T,K] @ w[N,K]^T (+bias) (gelu) (+res).  Returns (y, aux) ; aux = pre-activation."""
+    T, K = x2.shape
+    N = w.shape[0]
+    out_dtype = out_dtype or x2.dtype
+    y = torch.empty((T, N), dtype=out_dtype, device=x2.device)
+    aux = torch.empty((T, N), dtype=x2.dtype, device=x2.device) if want_aux else None
+    gemm_raw(_dt(x2), T, N, K, x2, x2.stride(0), 1, w, w.stride(0), 1, y, N, _dt(y), epi, bias, res,
+             res.stride(0) if res is not None else 0, aux, N if want_aux else 0)
+    return y, aux
+
+
+def linear_bwd_x(dy2, w, epi=EPI_NONE, aux=None):
+    """dx[T,K] = dy2[T,N] @ w[N,K]   (optionally times gelu'(aux))."""
+    T, N = dy2.shape
+    K = w.shape[1]
+    dx = torch.empty((T, K), dtype=dy2.dtype, device=dy2.device)
+    gemm_raw(_dt(dy2), T, K, N, dy2, dy2.stride(0), 1, w, 1, w.stride(0), dx, K, _dt(dx), epi, None, None, 0, aux,
+             K if aux is not None else 0)
+    return dx
+
+
+def linear_bwd_w(dy2, x2):
+    """dw[N,K] (fp32) = dy2[T,N]^T @ x2[T,K]."""
+    T, N = dy2.shape
+    K = x2.shape[1]
+    dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
+    gemm_raw(_dt(dy2), N, K, T, dy2, 1, dy2.stride(0), x2, 1, x2.stride(0), dw, K, F32)
+    return dw
+
+
+def colsum(x2):
+    rows, cols = x2.shape
+    out = torch.empty(cols, dtype=torch.float32, device=x2.device)
+    ws = _ws(lib.vitmi_colsum_workspace_bytes(rows, cols), x2.device)
+    check(lib.vitmi_colsum(_p(x2), _dt(x2), rows, cols, x2.stride(0), _p(out), _p(ws), _stream()), "vitmi_colsum")
+    return out
+
+
+def layernorm_fwd(x2, gamma, beta, eps):
+    """x2: [rows, D] with unit column stride (row stride free).  Returns (y dense, mean, rstd)."""
+    rows, D = x2.shape
+    y = torch.empty((rows, D), dtype=x2.dtype, device=x2.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    check(lib.vitmi_layernorm_fwd(_p(x2), x2.stride(0), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _dt(x2), rows,
+                                  D, eps, _stream()), "vitmi_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy2, x2, gamma, mean, rstd, dres=None, need_affine=True):
+    rows, D = x2.shape
+    dx = torch.empty((rows, D), dtype=x2.dtype, device=x2.device)
+    dg = torch.empty(D, dtype=torch.float32, device=x2.device) if need_affine else None
+    db = torch.empty(D, dtype=torch.float32, device=x2.device) if need_affine else None
+    ws = _ws(lib.vitmi_layernorm_bwd_workspace_bytes(rows, D), x2.device)
+    check(lib.vitmi_layernorm_bwd(_p(dy2), _p(x2), x2.stride(0), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
+                                  _p(dg), _p(db), _p(ws), _dt(x2), rows, D, _stream()), "vitmi_layernorm_bwd")
+    return dx, dg, db
+
+
+def attn_fwd(qkv, B, N, H, DH, want_probs):
+    I = H * DH
+    out = torch.empty((B, N, I), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+    probs = torch.empty((B, H, N, N), dtype=qkv.dtype, device=qkv.device) if want_probs else None
+    check(lib.vitmi_attn_fwd(_p(qkv), _p(out), _p(lse), _p(probs), _dt(qkv), B, N, H, DH, _stream()), "vitmi_attn_fwd")
+    return out, lse, probs
+
+
+def attn_bwd(qkv, out, dout, lse, B, N, H, DH):
+    dqkv = torch.empty_like(qkv)
+    ws = _ws(lib.vitmi_attn_bwd_workspace_bytes(_dt(qkv), B, N, H, DH), qkv.device)
+    check(lib.vitmi_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), None, _p(dqkv), _p(ws), _dt(qkv), B, N, H, DH,
+                             _stream()), "vitmi_attn_bwd")
+    return dqkv
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    check(lib.vitmi_add(_p(a), _p(b), _p(y), _dt(a), a.numel(), _stream()), "vitmi_add")
+    return y
+
+
+def _as2d(x):
+    """[..., D] -> [rows, D] view with unit column stride (copies only if the layout forbids a view)."""
+    D = x.shape[-1]
+    if x.dim() == 2 and x.stride(1) == 1:
+        return x
+    if x.is_contiguous():
+        return x.view(-1, D)
+    return x.contiguous().view(-1, D)
+
+
+# ---------------------------------------------------------------------------------------------
+# autograd functions
+# ---------------------------------------------------------------------------------------------
+class PatchEmbedFn(torch.autograd.Function):
+    """Conv2d(k=s=p)+bias then flatten/transpose (mymodel/ViT.py:33,43) -> [B, tokens, D]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cdt):
+        _need_gpu(x, weight)
+        B, C, H, W = x.shape
+        D, _, p, _ = weight.shape
+        per = (H // p) * (W // p)
+        if x.dtype not in _DT:
+            x = x.float()
+        if cdt == torch.float32 and x.dtype != torch.float32:
+            x = x.float()
+        x = x.contiguous()
+        w_c = compute_copy(weight, cdt).view(D, C * p * p)
+        out = torch.empty((B, per, D), dtype=cdt, device=x.device)
+        bias_f = bias.detach().float() if bias is not None else None
+        check(lib.vitmi_patch_embed_fwd(_p(x), _dt(x), _p(w_c), _p(bias_f), _p(out), _dt(cdt), B, C, H, W, p, D,
+                                        per * D, _stream()), "vitmi_patch_embed_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.cdt = cdt
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, C, H, W = x.shape
+        D, _, p, _ = weight.shape
+        per = (H // p) * (W // p)
+        dy = dy.contiguous()
+        dw = torch.empty((D, C * p * p), dtype=torch.float32, device=x.device)
+        check(lib.vitmi_patch_embed_bwd_w(_p(x), _dt(x), _p(dy), per * D, _p(dw), _dt(dy), B, C, H, W, p, D,
+                                          _stream()), "vitmi_patch_embed_bwd_w")
+        db = colsum(dy.view(B * per, D)) if ctx.has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w_c = compute_copy(weight, ctx.cdt).view(D, C * p * p)
+            dpatch = linear_bwd_x(dy.view(B * per, D), w_c)          # [B*per, C*p*p]
+            gh, gw = H // p, W // p
+            dx = dpatch.view(B, gh, gw, C, p, p).permute(0, 3, 1, 4, 2, 5).reshape(B, C, H, W).to(x.dtype)
+        return dx, dw.view_as(weight).to(weight.dtype), (db.to(weight.dtype) if db is not None else None), None
+
+
+class TokensFn(torch.autograd.Function):
+    """cls prepend + positional-embedding add, rows of the table chosen by seq_ord
+    (mymodel/ViT.py:155-159, ViT_mask.py:156-172)."""
+
+    @staticmethod
+    def forward(ctx, patch, cls, pe2d, seq_ord):
+        _need_gpu(patch, cls, pe2d, seq_ord)
+        B, n1, D = patch.shape
+        N = n1 + 1
+        patch = patch.contiguous()
+        cls_f = cls.detach().reshape(D).float().contiguous()
+        pe_f = pe2d.detach().float().contiguous() if pe2d is not None else None
+        out = torch.empty((B, N, D), dtype=patch.dtype, device=patch.device)
+        check(lib.vitmi_tokens_assemble_fwd(_p(patch), _p(cls_f), _p(pe_f), _p(seq_ord), _p(out), _dt(patch), B, N, D,
+                                            _stream()), "vitmi_tokens_assemble_fwd")
+        ctx.seq_ord = seq_ord
+        ctx.pe_shape = None if pe2d is None else tuple(pe2d.shape)
+        ctx.cls_shape = tuple(cls.shape)
+        ctx.pdtypes = (cls.dtype, None if pe2d is None else pe2d.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        dx = dx.contiguous()
+        B, N, D = dx.shape
+        dcls = torch.empty(D, dtype=torch.float32, device=dx.device)
+        rows = ctx.pe_shape[0] if ctx.pe_shape is not None else 0
+        dpe = torch.empty((rows, D), dtype=torch.float32, device=dx.device) if rows else None
+        ws = _ws(lib.vitmi_tokens_assemble_bwd_workspace_bytes(N, D), dx.device)
+        check(lib.vitmi_tokens_assemble_bwd(_p(dx), _p(ctx.seq_ord), _p(dcls), _p(dpe), rows, _p(ws), _dt(dx), B, N,
+                                            D, _stream()), "vitmi_tokens_assemble_bwd")
+        return (dx[:, 1:, :], dcls.view(ctx.cls_shape).to(ctx.pdtypes[0]),
+                dpe.to(ctx.pdtypes[1]) if dpe is not None else None, None)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim (mymodel/ViT.py:55,147)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_gpu(x, gamma)
+        x2 = _as2d(x)
+        g = gamma.detach().float()
+        b = beta.detach().float()
+        y, mean, rstd = layernorm_fwd(x2, g, b, eps)
+        ctx.save_for_backward(x2, g, mean, rstd)
+        ctx.shape = x.shape
+        ctx.pdtype = gamma.dtype
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd = ctx.saved_tensors
+        dx, dg, db = layernorm_bwd(_as2d(dy.contiguous()), x2, g, mean, rstd)
+        return dx.view(ctx.shape), dg.to(ctx.pdtype), db.to(ctx.pdtype), None
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear (mymodel/ViT.py:148 head; also the stand-alone projections)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cdt, out_dtype):
+        _need_gpu(x, weight)
+        x2 = _as2d(x)
+        if x2.dtype != cdt:
+            x2 = cast(x2, cdt)
+        w_c = compute_copy(weight, cdt)
+        bias_f = bias.detach().float() if bias is not None else None
+        y, _ = linear_fwd(x2, w_c, bias_f, out_dtype=out_dtype)
+        ctx.save_for_backward(x2, weight)
+        ctx.cdt = cdt
+        ctx.in_shape = x.shape
+        ctx.in_dtype = x.dtype
+        ctx.has_bias = bias is not None
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = _as2d(dy.contiguous())
+        if dy2.dtype != ctx.cdt:
+            dy2 = cast(dy2, ctx.cdt)
+        w_c = compute_copy(weight, ctx.cdt)
+        dx = linear_bwd_x(dy2, w_c).view(ctx.in_shape)
+        if dx.dtype != ctx.in_dtype:
+            dx = cast(dx, ctx.in_dtype)
+        dw = linear_bwd_w(dy2, x2).to(weight.dtype)
+        db = colsum(dy2).to(weight.dtype) if ctx.has_bias else None
+        return dx, dw, db, None, None
+
+
+class AttnBlockFn(torch.autograd.Function):
+    """[LayerNorm ->] to_qkv -> softmax(q k^T * scale) v -> [to_out] [+ x]
+    (mymodel/ViT.py:58, 93-104, 119) as one autograd node.
+
+    Returns (y, probs); probs is the [B,H,N,N] post-softmax tensor when export is requested
+    (the tensor the reference exposes to forward hooks on Attention.attend), else None.
+    """
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, eps, add_residual, want_probs, cdt):
+        _need_gpu(x, w_qkv)
+        B, N, D = x.shape
+        x2 = _as2d(x)
+        if x2.dtype != cdt:
+            x2 = cast(x2, cdt)
+        inner = w_qkv.shape[0] // 3
+        dh = inner // heads
+        if ln_w is not None:
+            g = ln_w.detach().float()
+            xn, mean, rstd = layernorm_fwd(x2, g, ln_b.detach().float(), eps)
+        else:
+            g = mean = rstd = None
+            xn = x2
+        wq = compute_copy(w_qkv, cdt)
+        qkv, _ = linear_fwd(xn, wq)
+        o, lse, probs = attn_fwd(qkv, B, N, heads, dh, want_probs)
+        o2 = o.view(B * N, inner)
+        if w_out is not None:
+            wo = compute_copy(w_out, cdt)
+            y, _ = linear_fwd(o2, wo, b_out.detach().float() if b_out is not None else None,
+                              res=x2 if add_residual else None)
+        else:
+            y = add(o2, x2) if add_residual else o2
+        ctx.save_for_backward(x2, g, mean, rstd, xn if ln_w is not None else None, qkv, o, lse, w_qkv, w_out)
+        ctx.meta = (B, N, D, heads, dh, add_residual, cdt, ln_w is not None, b_out is not None,
+                    ln_w.dtype if ln_w is not None else None, x.dtype)
+        if probs is not None:
+            ctx.mark_non_differentiable(probs)
+        return y.view(B, N, -1), probs
+
+    @staticmethod
+    def backward(ctx, dy, _dprobs):
+        x2, g, mean, rstd, xn, qkv, o, lse, w_qkv, w_out = ctx.saved_tensors
+        B, N, D, heads, dh, add_residual, cdt, has_ln, has_bo, ln_dtype, in_dtype = ctx.meta
+        inner = heads * dh
+        dy2 = _as2d(dy.contiguous())
+        if dy2.dtype != cdt:
+            dy2 = cast(dy2, cdt)
+        if xn is None:
+            xn = x2
+        o2 = o.view(B * N, inner)
+        dwo = dbo = None
+        if w_out is not None:
+            wo = compute_copy(w_out, cdt)
+            dwo = linear_bwd_w(dy2, o2).to(w_out.dtype)
+            dbo = colsum(dy2).to(w_out.dtype) if has_bo else None
+            do = linear_bwd_x(dy2, wo)
+        else:
+            do = dy2
+        dqkv = attn_bwd(qkv, o, do.view(B, N, inner), lse, B, N, heads, dh)
+        dqkv2 = dqkv.view(B * N, 3 * inner)
+        wq = compute_copy(w_qkv, cdt)
+        dwq = linear_bwd_w(dqkv2, xn).to(w_qkv.dtype)
+        dxn = linear_bwd_x(dqkv2, wq)
+        dg = db = None
+        if has_ln:
+            dx, dg, db = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None)
+            dg, db = dg.to(ln_dtype), db.to(ln_dtype)
+        else:
+            dx = add(dxn, dy2) if add_residual else dxn
+        dx = dx.view(B, N, D)
+        if dx.dtype != in_dtype:
+            dx = cast(dx, in_dtype)
+        return dx, dg, db, dwq, dwo, dbo, None, None, None, None, None
+
+
+class FFBlockFn(torch.autograd.Function):
+    """[LayerNorm ->] Linear -> GELU(erf) -> Linear [+ x]  (mymodel/ViT.py:58, 65-73, 120)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, add_residual, cdt):
+        _need_gpu(x, w1)
+        shape = x.shape
+        x2 = _as2d(x)
+        if x2.dtype != cdt:
+            x2 = cast(x2, cdt)
+        if ln_w is not None:
+            g = ln_w.detach().float()
+            xn, mean, rstd = layernorm_fwd(x2, g, ln_b.detach().float(), eps)
+        else:
+            g = mean = rstd = None
+            xn = x2
+        h, u = linear_fwd(xn, compute_copy(w1, cdt), b1.detach().float(), epi=EPI_GELU, want_aux=True)
+        y, _ = linear_fwd(h, compute_copy(w2, cdt), b2.detach().float(), res=x2 if add_residual else None)
+        ctx.save_for_backward(x2, g, mean, rstd, xn if ln_w is not None else None, u, h, w1, w2)
+        ctx.meta = (shape, add_residual, cdt, ln_w is not None, ln_w.dtype if ln_w is not None else None, x.dtype)
+        return y.view(*shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd, xn, u, h, w1, w2 = ctx.saved_tensors
+        shape, add_residual, cdt, has_ln, ln_dtype, in_dtype = ctx.meta
+        dy2 = _as2d(dy.contiguous())
+        if dy2.dtype != cdt:
+            dy2 = cast(dy2, cdt)
+        if xn is None:
+            xn = x2
+        dw2 = linear_bwd_w(dy2, h).to(w2.dtype)
+        db2 = colsum(dy2).to(w2.dtype)
+        du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u)
+        dw1 = linear_bwd_w(du, xn).to(w1.dtype)
+        db1 = colsum(du).to(w1.dtype)
+        dxn = linear_bwd_x(du, compute_copy(w1, cdt))
+        dg = db = None
+        if has_ln:
+            dx, dg, db = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None)
+            dg, db = dg.to(ln_dtype), db.to(ln_dtype)
+        else:
+            dx = add(dxn, dy2) if add_residual else dxn
+        dx = dx.view(shape)
+        if dx.dtype != in_dtype:
+            dx = cast(dx, in_dtype)
+        return dx, dg, db, dw1, db1, dw2, db2, None, None, None
+
+
+class MeanPoolFn(torch.autograd.Function):
+    """x.mean(dim=1) for pool == 'mean' (mymodel/ViT.py:164)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x)
+        x = x.contiguous()
+        B, N, D = x.shape
+        out = torch.empty((B, D), dtype=x.dtype, device=x.device)
+        check(lib.vitmi_meanpool_fwd(_p(x), _p(out), _dt(x), B, N, D, _stream()), "vitmi_meanpool_fwd")
+        ctx.n = N
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        B, D = dout.shape
+        dx = torch.empty((B, ctx.n, D), dtype=dout.dtype, device=dout.device)
+        check(lib.vitmi_meanpool_bwd(_p(dout), _p(dx), _dt(dout), B, ctx.n, D, _stream()), "vitmi_meanpool_bwd")
+        return dx
