@@ -28,7 +28,7 @@ def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
 
 def q(t, dtype):
     """value the kernel really sees: rounded to the compute dtype, back in fp32 on the CPU"""
-    return t.to(dtype).float()
+    return t.detach().to(dtype).float().clone()
 
 
 # ------------------------------------------------------------------------------------------ GEMM
@@ -130,8 +130,8 @@ def test_tokens_assemble(ops, dtype, masked):
         seq = vit_oracle.seq_ord_from_mask(m, N).squeeze(0)
     pr, cr, per = q(patch, dtype).requires_grad_(True), cls.clone().requires_grad_(True), pe.clone().requires_grad_(True)
     ref = torch.cat([cr.expand(B, -1, -1), pr], 1) + (per[seq] if masked else per[:N])
-    pd = patch.to(DEV, dtype).requires_grad_(True)
-    cd, ped = cls.to(DEV).requires_grad_(True), pe.to(DEV).requires_grad_(True)
+    pd = patch.detach().to(DEV, dtype).requires_grad_(True)
+    cd, ped = cls.detach().to(DEV).requires_grad_(True), pe.detach().to(DEV).requires_grad_(True)
     out = ops.TokensFn.apply(pd, cd, ped, seq.to(DEV) if masked else None)
     assert rel_err(out, ref) < TOL[dtype]
     dy = rnd(B, N, D, seed=4)
@@ -163,11 +163,11 @@ def test_tokens_gradient_is_deterministic(ops):
 @pytest.mark.parametrize("img,p,C,D,B", [(32, 4, 3, 96, 3), (64, 16, 3, 128, 2), (224, 16, 3, 64, 1), (24, 8, 1, 40, 2)])
 def test_patch_embed(ops, dtype, img, p, C, D, B):
     x, w, b = rnd(B, C, img, img, seed=1), rnd(D, C, p, p, seed=2, scale=(C * p * p) ** -0.5), rnd(D, seed=3)
-    xr = (q(x, dtype) if dtype == torch.bfloat16 else x).requires_grad_(True)
+    xr = q(x, dtype).requires_grad_(True)
     wr, br = q(w, dtype).requires_grad_(True), b.clone().requires_grad_(True)
     ref = vit_oracle.patch_embed(xr, wr, br)
-    xd = x.to(DEV).requires_grad_(True)
-    wd, bd = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    wd, bd = w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
     out = ops.PatchEmbedFn.apply(xd, wd, bd, dtype)
     assert out.shape == ref.shape and rel_err(out, ref) < TOL[dtype]
     dy = rnd(*ref.shape, seed=4)
