@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train images/sec of ViT-B/16 224 px (ImageNet100-shaped synthetic data)
+on N MI355X, bf16 MFMA kernels, fp32 master weights + Adam, one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + CE loss + backward (+ bucketed gradient all-reduce when N > 1) + Adam step
+on one batch of 256 images per GPU that is already resident in HBM.  Rank 0 prints one JSON
+line.  `roofline` describes the dominant kernel family (per-launch HIP-event timing inside the
+timed region); `cpu_baseline` is the CPU oracle timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak of one MI355X (vendor spec, no sparsity)
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (ctor args, masked?, per-GPU batch, classes, train GFLOP/img = 6 * fwd MACs)
+    "vit_b16_224": (dict(image_size=224, patch_size=16, embed_dim=768, num_classes=100, depth=12, heads=12,
+                         mlp_dim=3072, dim_head=64), False, 256, 105.378822144),
+    "cifar_mask": (dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=12, heads=12,
+                        mlp_dim=512), True, 256, 1.327),
+}
+
+
+def fwd_macs(kw, channels=3):
+    n1 = (kw["image_size"] // kw["patch_size"]) ** 2
+    N, D, L, H = n1 + 1, kw["embed_dim"], kw["depth"], kw["heads"]
+    dh = kw.get("dim_head", 8)
+    I, M = H * dh, kw["mlp_dim"]
+    return n1 * D * channels * kw["patch_size"] ** 2 + L * (N * D * 3 * I + 2 * H * N * N * dh + N * I * D
+                                                           + 2 * N * D * M) + D * kw["num_classes"]
+
+
+def cpu_baseline(kw, masked, seconds_budget=20.0):
+    """The CPU oracle (pure-torch restatement of the reference) on the host cores: a bounded
+    sample of the same workload -- batch 8, one warm-up step then timed steps."""
+    from oracle import vit_oracle
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    B = 8
+    params = vit_oracle.init_params(masked=masked, seed=1001, **kw)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, 3, kw["image_size"], kw["image_size"], generator=g)
+    y = torch.randint(0, kw["num_classes"], (B,), generator=g)
+    vit_oracle.loss_and_grads(params, x, y, kw["heads"])
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 3 or (time.perf_counter() - t0 < seconds_budget and steps < 8):
+        vit_oracle.loss_and_grads(params, x, y, kw["heads"])
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd fp32, batch {B}, {steps} timed steps after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="vit_b16_224", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timers", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from visiontransformer_amd import ViT, ViT_mask, _lib
+    from visiontransformer_amd.optim import FusedAdam
+    from visiontransformer_amd.parallel import GradReducer, broadcast_parameters
+
+    kw, masked, batch, gflop_img = WORKLOADS[args.workload]
+    if args.batch:
+        batch = args.batch
+    torch.manual_seed(1001)
+    model = (ViT_mask if masked else ViT).VIT(**kw).to(dev)
+    if masked:
+        model.train_method = "mask"
+    model.train()
+    reducer = None
+    if world > 1:
+        broadcast_parameters(model, src=0)
+        reducer = GradReducer(model, bucket_mb=64)
+    opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=5e-5)
+
+    torch.manual_seed(1234 + rank)
+    x = torch.randn(batch, 3, kw["image_size"], kw["image_size"], device=dev)
+    y = torch.randint(0, kw["num_classes"], (batch,), device=dev)
+    unk = None
+    if masked:
+        import random
+        import numpy as np
+        from visiontransformer_amd.masking_generator import MaskingGenerator
+        grid = kw["image_size"] // kw["patch_size"]
+        gen = MaskingGenerator((grid, grid), grid * grid // 2, min_num_patches=4)
+
+    def step(i):
+        nonlocal unk
+        if masked:
+            random.seed(1234 + i), np.random.seed(1234 + i)
+            flat, _, _ = gen.masked_indexes()
+            unk = torch.from_numpy(MaskingGenerator.unk_mask_from_flat(flat)).long().to(dev, non_blocking=True)
+        opt.zero_grad(set_to_none=True)
+        logits = model(x, unk_mask=unk) if masked else model(x)
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    timers = not args.no_kernel_timers
+    sync()
+    if timers:
+        _lib.check(_lib.lib.vitmi_prof_reset())
+        _lib.check(_lib.lib.vitmi_prof_enable(1))
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    if timers:
+        _lib.check(_lib.lib.vitmi_prof_enable(0))
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        imgs = batch * world * args.steps
+        value = imgs / dt
+        fams = []
+        if timers:
+            for fam in range(_lib.FAM_COUNT):
+                ms, work, n = _lib.prof_read(fam)
+                if n:
+                    fams.append({"family": _lib.lib.vitmi_prof_name(fam).decode(), "ms": ms, "work": work, "launches": n})
+            fams.sort(key=lambda f: -f["ms"])
+        roof = None
+        if fams:
+            gemm = [f for f in fams if f["family"].startswith("gemm")]
+            dom = fams[0]
+            is_flop = dom["family"].startswith(("gemm", "attn"))
+            achieved = dom["work"] / (dom["ms"] * 1e-3) / (1e12 if is_flop else 1e9)
+            peak = MFMA_PEAK_TFLOPS if is_flop else HBM_PEAK_GBS
+            roof = {"bound": "mfma" if is_flop else "hbm", "achieved": achieved, "peak": peak,
+                    "unit": "TFLOP/s" if is_flop else "GB/s", "frac": achieved / peak, "traffic": None,
+                    "kernel": dom["family"], "launches": dom["launches"],
+                    "avg_launch_ms": dom["ms"] / dom["launches"],
+                    "all_gemm_tflops": (sum(f["work"] for f in gemm) / (sum(f["ms"] for f in gemm) * 1e-3) / 1e12)
+                    if gemm else None,
+                    "time_share_ms_per_step": {f["family"]: round(f["ms"] / args.steps, 3) for f in fams}}
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(kw, masked)
+        step_tflops = value / world * gflop_img * 1e9 / 1e12
+        out = {
+            "metric": "train images/sec (node) ViT-B/16 224px" if args.workload == "vit_b16_224"
+            else f"train images/sec (node) {args.workload}",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {kw}, per-GPU batch {batch}, CE loss, fused Adam "
+                                   "(fp32 master weights), N(0,1) images resident in HBM",
+                       "global_batch": batch * world, "seq_len": (kw["image_size"] // kw["patch_size"]) ** 2 + 1,
+                       "parallelism": f"dp{world}"},
+            "train_gflop_per_image": gflop_img,
+            "step_mfma_frac_per_gpu": step_tflops / MFMA_PEAK_TFLOPS,
+            "final_loss": loss_val,
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,7 +45,11 @@ extern "C" {
 #define VITMI_FAM_LAYERNORM 3
 #define VITMI_FAM_TOKENS 4
 #define VITMI_FAM_OTHER 5
-#define VITMI_FAM_COUNT 6
+/* one family per bf16 GEMM kernel instantiation: VARIANT0 + 4*layout + epilogue/output, with
+ * layout = 2*(A stored [k][m]) + (B stored [k][n]) and epilogue/output in
+ * {plain->bf16, plain->f32, gelu->bf16, dgelu->bf16} */
+#define VITMI_FAM_GEMM_VARIANT0 8
+#define VITMI_FAM_COUNT 24
 
 int vitmi_version(void);
 const char* vitmi_last_error(void);
@@ -58,6 +62,7 @@ const char* vitmi_last_error(void);
 int vitmi_prof_enable(int on);
 int vitmi_prof_reset(void);
 int vitmi_prof_read(int family, double* total_ms, double* total_work, long long* launches);
+const char* vitmi_prof_name(int family);
 
 /* dst[i] = (dst_dt) src[i].  Replaces Tensor.to(dtype) on parameters/inputs. */
 int vitmi_cast(const void* src, int src_dt, void* dst, int dst_dt, long long n, void* stream);

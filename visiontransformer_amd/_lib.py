@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvitmi_hip.so")
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
 FAM_GEMM, FAM_ATTN_FWD, FAM_ATTN_BWD, FAM_LAYERNORM, FAM_TOKENS, FAM_OTHER = range(6)
+FAM_GEMM_VARIANT0, FAM_COUNT = 8, 24
 
 P, I, L, F = c_void_p, c_int, c_longlong, c_float
 
@@ -23,6 +24,7 @@ SIGNATURES = {
     "vitmi_prof_enable": (I, [I]),
     "vitmi_prof_reset": (I, []),
     "vitmi_prof_read": (I, [I, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(c_longlong)]),
+    "vitmi_prof_name": (c_char_p, [I]),
     "vitmi_cast": (I, [P, I, P, I, L, P]),
     "vitmi_gemm": (I, [I, I, I, I, P, L, L, P, L, L, P, L, I, I, P, P, L, P, L, P]),
     "vitmi_colsum_workspace_bytes": (L, [L, I]),
@@ -48,7 +50,7 @@ SIGNATURES = {
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -m visiontransformer_amd.build` "
+            f"{LIB_PATH} is missing: build it with `python visiontransformer_amd/build.py` "
             "(hipcc --offload-arch=gfx950).  This package has no other compute path.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():

@@ -1,4 +1,4 @@
-"""Builds libvitmi_hip.so (gfx950) in-tree with hipcc.  `python -m visiontransformer_amd.build`.
+"""Builds libvitmi_hip.so (gfx950) in-tree with hipcc.  `python visiontransformer_amd/build.py`.
 
 The library is plain HIP + C ABI (no torch headers), so a build is a handful of hipcc
 invocations; objects are cached under csrc/build/ and rebuilt when their source or a header

@@ -348,7 +348,13 @@ extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long 
     VITMI_CHECK_ARG(sam > 0 && sak > 0 && sbn > 0 && sbk > 0, "vitmi_gemm: strides must be positive");
     hipStream_t s = as_stream(stream);
     Epilogue epi{C, ldc, bias, residual, ldr, aux, ldaux, 0, 0};
-    ProfScope prof(VITMI_FAM_GEMM, s, 2.0 * M * N * K);
+    int fam = VITMI_FAM_GEMM;
+    if (dt == VITMI_BF16) {
+        const int layout = ((sam == 1 && sak != 1) ? 2 : 0) + ((sbn == 1 && sbk != 1) ? 1 : 0);
+        const int eo = c_dt == VITMI_F32 ? 1 : (epilogue == VITMI_EPI_GELU ? 2 : (epilogue == VITMI_EPI_DGELU ? 3 : 0));
+        fam = VITMI_FAM_GEMM_VARIANT0 + 4 * layout + eo;
+    }
+    ProfScope prof(fam, s, 2.0 * M * N * K);
     if (dt == VITMI_F32) {
         VITMI_CHECK_ARG(c_dt == VITMI_F32, "vitmi_gemm: fp32 compute writes fp32 output");
         F32Operand a{(const float*)A, sam, sak, M, 0, 0, 0, 0, 0, 0, 0, 0};

@@ -41,14 +41,26 @@ struct Family {
 std::mutex g_mu;
 bool g_on = false;
 Family g_fam[VITMI_FAM_COUNT];
+std::vector<hipEvent_t> g_pool;  // recycled events: creating one per launch would cost more than recording it
+
+hipEvent_t take_event() {
+    if (!g_pool.empty()) {
+        hipEvent_t e = g_pool.back();
+        g_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
 }  // namespace
 
 void vitmi_prof_record_begin(int family, hipStream_t s, double work) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Family& f = g_fam[family];
-    hipEvent_t a;
-    if (hipEventCreate(&a) != hipSuccess) return;
+    hipEvent_t a = take_event();
+    if (!a) return;
     (void)hipEventRecord(a, s);
     f.pending = a;
     f.pending_work = work;
@@ -59,8 +71,8 @@ void vitmi_prof_record_end(int family, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     Family& f = g_fam[family];
     if (!f.pending) return;
-    hipEvent_t b;
-    if (hipEventCreate(&b) != hipSuccess) return;
+    hipEvent_t b = take_event();
+    if (!b) return;
     (void)hipEventRecord(b, s);
     f.pairs.push_back({f.pending, b, f.pending_work});
     f.pending = nullptr;
@@ -76,11 +88,11 @@ extern "C" int vitmi_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& f : g_fam) {
         for (auto& p : f.pairs) {
-            (void)hipEventDestroy(p.a);
-            (void)hipEventDestroy(p.b);
+            g_pool.push_back(p.a);
+            g_pool.push_back(p.b);
         }
         f.pairs.clear();
-        if (f.pending) (void)hipEventDestroy(f.pending);
+        if (f.pending) g_pool.push_back(f.pending);
         f.pending = nullptr;
     }
     return VITMI_OK;
@@ -105,4 +117,18 @@ extern "C" int vitmi_prof_read(int family, double* total_ms, double* total_work,
     if (total_work) *total_work = work;
     if (launches) *launches = n;
     return VITMI_OK;
+}
+
+extern "C" const char* vitmi_prof_name(int family) {
+    static const char* fixed[] = {"gemm(other)", "attn_fwd", "attn_bwd", "layernorm", "tokens", "other"};
+    static const char* layout[] = {"A[m][k] B[n][k]", "A[m][k] B[k][n]", "A[k][m] B[n][k]", "A[k][m] B[k][n]"};
+    static const char* epi[] = {"plain->bf16", "plain->f32", "gelu->bf16", "dgelu->bf16"};
+    static thread_local char buf[128];
+    if (family >= 0 && family < VITMI_FAM_GEMM_VARIANT0) return fixed[family];
+    if (family >= VITMI_FAM_GEMM_VARIANT0 && family < VITMI_FAM_COUNT) {
+        const int v = family - VITMI_FAM_GEMM_VARIANT0;
+        snprintf(buf, sizeof(buf), "gemm_bf16_kernel[%s, %s]", layout[v >> 2], epi[v & 3]);
+        return buf;
+    }
+    return "?";
 }
