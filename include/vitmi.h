@@ -49,7 +49,11 @@ extern "C" {
  * layout = 2*(A stored [k][m]) + (B stored [k][n]) and epilogue/output in
  * {plain->bf16, plain->f32, gelu->bf16, dgelu->bf16} */
 #define VITMI_FAM_GEMM_VARIANT0 8
-#define VITMI_FAM_COUNT 24
+/* aligned fast paths: nt (both operands contiguous along k) x the same four epilogue/output
+ * forms, and tn (weight gradients, split over tokens) */
+#define VITMI_FAM_GEMM_NT_FAST0 24
+#define VITMI_FAM_GEMM_TN_FAST 28
+#define VITMI_FAM_COUNT 29
 
 int vitmi_version(void);
 const char* vitmi_last_error(void);
@@ -77,6 +81,19 @@ int vitmi_cast(const void* src, int src_dt, void* dst, int dst_dt, long long n, 
 int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long sam, long long sak, const void* B,
                long long sbn, long long sbk, void* C, long long ldc, int c_dt, int epilogue, const float* bias,
                const void* residual, long long ldr, void* aux, long long ldaux, void* stream);
+
+/* Weight gradient C[p][q] (fp32, row stride ldc) = sum_t U[t][p] * V[t][q]: U is [T,P] (row
+ * stride ldu), V is [T,Q] (row stride ldv), both `dt`.  For y = x W^T: dW = wgrad(U = dy, V = x).
+ * The contraction over tokens is split into slabs summed in a fixed order (deterministic);
+ * workspace holds the slabs.  Replaces the weight-gradient GEMM of nn.Linear's backward. */
+long long vitmi_gemm_wgrad_workspace_bytes(int dt, int P, int Q, int T);
+int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv,
+                     float* C, long long ldc, void* workspace, void* stream);
+
+/* dst[c][r] (bf16) = src[r][c] (src_dt): the transposed bf16 compute copy of a weight, which
+ * turns the input-gradient product dX = dY W into the k-contiguous form of vitmi_gemm.  No
+ * reference counterpart (aten reads W through strides). */
+int vitmi_transpose_cast(const void* src, int src_dt, void* dst, int rows, int cols, void* stream);
 
 /* out[c] = sum_r x[r*ld + c] in fp32 (bias gradients).  workspace: vitmi_colsum_workspace_bytes.
  * Replaces the bias-gradient reductions autograd runs for nn.Linear / nn.Conv2d. */

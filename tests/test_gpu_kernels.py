@@ -245,3 +245,43 @@ def test_cast_add_meanpool(ops):
     assert rel_err(m, t.detach().cpu().mean(1)) < 1e-6
     m.sum().backward()
     assert rel_err(t.grad, torch.full((3, 17, 40), 1 / 17)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ aligned fast paths
+@pytest.mark.parametrize("M,N,K", [(394, 768, 768), (1000, 2304, 768), (520, 768, 3072), (129, 136, 72), (5, 8, 8),
+                                   (256, 256, 4096)])
+def test_fast_nt_gemm_all_epilogues(ops, M, N, K):
+    dtype = torch.bfloat16
+    x, w, b, r = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23), rnd(M, N, seed=24)
+    xd, wd, bd, rd = x.to(DEV, dtype), w.to(DEV, dtype), b.to(DEV), r.to(DEV, dtype)
+    pre = q(x, dtype) @ q(w, dtype).t() + b
+    y, _ = ops.linear_fwd(xd, wd, bd, res=rd)
+    assert rel_err(y, pre + q(r, dtype)) < 1e-2
+    h, u = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_GELU, want_aux=True)
+    assert rel_err(u, pre) < 1e-2 and rel_err(h, vit_oracle.gelu_erf(pre)) < 1e-2
+    y32, _ = ops.linear_fwd(xd, wd, None, out_dtype=torch.float32)
+    assert rel_err(y32, pre - b) < 2e-3
+    # input gradient through the transposed weight copy, with and without the dGELU epilogue
+    wp = torch.nn.Parameter(w.to(DEV))
+    wt = ops.compute_copy_t(wp, dtype)
+    assert torch.equal(wt.cpu(), w.to(dtype).t().contiguous())
+    dy = rnd(M, N, seed=25)
+    dx = ops.linear_bwd_x(dy.to(DEV, dtype), wd, w_t=wt)
+    assert rel_err(dx, q(dy, dtype) @ q(w, dtype)) < 1e-2
+    aux = rnd(M, K, seed=26).to(DEV, dtype)
+    du = ops.linear_bwd_x(dy.to(DEV, dtype), wd, epi=ops.EPI_DGELU, aux=aux, w_t=wt)
+    a = aux.float().cpu().requires_grad_(True)
+    vit_oracle.gelu_erf(a).backward(q(dy, dtype) @ q(w, dtype))
+    assert rel_err(du, a.grad) < 1e-2
+
+
+@pytest.mark.parametrize("T,P,Q", [(6304, 768, 768), (1576, 2304, 768), (12608, 768, 3072), (197, 96, 192), (64, 8, 8),
+                                   (1000, 136, 520)])
+def test_fast_weight_gradient_gemm(ops, T, P, Q):
+    dtype = torch.bfloat16
+    dy, x = rnd(T, P, seed=31), rnd(T, Q, seed=32)
+    dw = ops.linear_bwd_w(dy.to(DEV, dtype), x.to(DEV, dtype))
+    ref = q(dy, dtype).double().t() @ q(x, dtype).double()
+    assert rel_err(dw, ref) < 1e-4                      # fp32 accumulation of exact bf16 products
+    dw2 = ops.linear_bwd_w(dy.to(DEV, dtype), x.to(DEV, dtype))
+    assert torch.equal(dw, dw2)                         # slab order is fixed: bitwise reproducible

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvitmi_hip.so")
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
 FAM_GEMM, FAM_ATTN_FWD, FAM_ATTN_BWD, FAM_LAYERNORM, FAM_TOKENS, FAM_OTHER = range(6)
-FAM_GEMM_VARIANT0, FAM_COUNT = 8, 24
+FAM_GEMM_VARIANT0, FAM_COUNT = 8, 29
 
 P, I, L, F = c_void_p, c_int, c_longlong, c_float
 
@@ -27,6 +27,9 @@ SIGNATURES = {
     "vitmi_prof_name": (c_char_p, [I]),
     "vitmi_cast": (I, [P, I, P, I, L, P]),
     "vitmi_gemm": (I, [I, I, I, I, P, L, L, P, L, L, P, L, I, I, P, P, L, P, L, P]),
+    "vitmi_gemm_wgrad_workspace_bytes": (L, [I, I, I, I]),
+    "vitmi_gemm_wgrad": (I, [I, I, I, I, P, L, P, L, P, L, P, P]),
+    "vitmi_transpose_cast": (I, [P, I, P, I, I, P]),
     "vitmi_colsum_workspace_bytes": (L, [L, I]),
     "vitmi_colsum": (I, [P, I, L, I, L, P, P, P]),
     "vitmi_patch_embed_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, L, P]),

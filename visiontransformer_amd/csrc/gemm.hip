@@ -14,6 +14,19 @@
 // elements straight from the NCHW image (no im2col buffer).
 #include "common.h"
 
+// fast paths for aligned bf16 problems (gemm_fast.hip)
+bool vitmi_gemm_nt_fast_ok(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
+                           const void* C, long long ldc, int c_dt, const void* res, long long ldr, const void* aux,
+                           long long ldaux);
+int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
+                       long long ldc, int c_dt, int epilogue, const float* bias, const void* residual, long long ldr,
+                       void* aux, long long ldaux, hipStream_t s);
+bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const void* V, long long ldv, const void* C,
+                           long long ldc);
+int vitmi_gemm_tn_slabs(int P, int Q, int T);
+int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
+                       long long ldc, float* slabs, hipStream_t s);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -349,12 +362,20 @@ extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long 
     hipStream_t s = as_stream(stream);
     Epilogue epi{C, ldc, bias, residual, ldr, aux, ldaux, 0, 0};
     int fam = VITMI_FAM_GEMM;
+    bool fast_nt = false;
     if (dt == VITMI_BF16) {
+        VITMI_CHECK_ARG(c_dt == VITMI_BF16 || (c_dt == VITMI_F32 && epilogue == VITMI_EPI_NONE),
+                        "vitmi_gemm: fp32 output supports only the plain epilogue");
         const int layout = ((sam == 1 && sak != 1) ? 2 : 0) + ((sbn == 1 && sbk != 1) ? 1 : 0);
         const int eo = c_dt == VITMI_F32 ? 1 : (epilogue == VITMI_EPI_GELU ? 2 : (epilogue == VITMI_EPI_DGELU ? 3 : 0));
         fam = VITMI_FAM_GEMM_VARIANT0 + 4 * layout + eo;
+        fast_nt = sak == 1 && sbk == 1 &&
+                  vitmi_gemm_nt_fast_ok(M, N, K, A, sam, B, sbn, C, ldc, c_dt, residual, ldr, aux, ldaux);
+        if (fast_nt) fam = VITMI_FAM_GEMM_NT_FAST0 + eo;
     }
     ProfScope prof(fam, s, 2.0 * M * N * K);
+    if (fast_nt)
+        return vitmi_gemm_nt_fast(M, N, K, A, sam, B, sbn, C, ldc, c_dt, epilogue, bias, residual, ldr, aux, ldaux, s);
     if (dt == VITMI_F32) {
         VITMI_CHECK_ARG(c_dt == VITMI_F32, "vitmi_gemm: fp32 compute writes fp32 output");
         F32Operand a{(const float*)A, sam, sak, M, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -370,8 +391,6 @@ extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long 
         return VITMI_OK;
     }
     VITMI_CHECK_ARG(dt == VITMI_BF16, "vitmi_gemm: bad dtype %d", dt);
-    VITMI_CHECK_ARG(c_dt == VITMI_BF16 || (c_dt == VITMI_F32 && epilogue == VITMI_EPI_NONE),
-                    "vitmi_gemm: fp32 output supports only the plain epilogue");
     // an operand is K-contiguous unless its row stride is 1 and its k stride is not
     const bool a_kc = !(sam == 1 && sak != 1);
     const bool b_kc = !(sbn == 1 && sbk != 1);
@@ -461,4 +480,24 @@ extern "C" int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, 
     }
     VITMI_LAUNCH_CHECK("vitmi_patch_embed_bwd_w(bf16)");
     return VITMI_OK;
+}
+
+extern "C" long long vitmi_gemm_wgrad_workspace_bytes(int dt, int P, int Q, int T) {
+    if (dt != VITMI_BF16) return 0;
+    const int ns = vitmi_gemm_tn_slabs(P, Q, T);
+    return ns > 1 ? (long long)ns * P * Q * (long long)sizeof(float) : 0;
+}
+
+extern "C" int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long long ldu, const void* V,
+                                long long ldv, float* C, long long ldc, void* workspace, void* stream) {
+    VITMI_CHECK_ARG(U && V && C, "vitmi_gemm_wgrad: null operand");
+    VITMI_CHECK_ARG(P > 0 && Q > 0 && T > 0 && ldu >= P && ldv >= Q && ldc >= Q, "vitmi_gemm_wgrad: bad shape");
+    hipStream_t s = as_stream(stream);
+    if (dt == VITMI_BF16 && ldc == Q && vitmi_gemm_tn_fast_ok(P, Q, U, ldu, V, ldv, C, ldc)) {
+        ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * P * Q * (double)T);
+        return vitmi_gemm_tn_fast(P, Q, T, U, ldu, V, ldv, C, ldc, (float*)workspace, s);
+    }
+    // general path: the strided GEMM with both operands read along their output index
+    return vitmi_gemm(dt, P, Q, T, U, 1, ldu, V, 1, ldv, C, ldc, VITMI_F32, VITMI_EPI_NONE, nullptr, nullptr, 0,
+                      nullptr, 0, stream);
 }

@@ -1,0 +1,476 @@
+// Fast bf16 GEMM kernels for the aligned shapes of the ViT encoder (16-byte-aligned operands,
+// leading dimensions and inner extents multiples of 8).  Both stage operands HBM -> LDS with
+// direct-to-LDS loads (global_load_lds, 16 B per lane, no VGPR round trip), double-buffered, one
+// barrier per 64-deep K-step, and compute 128x128 block tiles with 4 waves x (4x4)
+// v_mfma_f32_16x16x32_bf16 accumulators.
+//
+//   nt: C[m][n] = sum_k A[m][k] B[n][k]      both operands contiguous along k
+//       LDS image [row][64 k] (128-B rows); 16-B chunk c of row r sits at chunk
+//       c ^ swz_nt(r): the swizzle is applied to the per-lane SOURCE address of the direct-to-LDS
+//       load (its destination is lane-linear) and again on the ds_read_b128 of a fragment.
+//       The MFMA is issued "swapped" (weight rows as the A operand) and weight rows are taken
+//       in a permuted order so that a lane ends up with 16 consecutive n of one output row:
+//       bias / GELU / residual / store all work on 32-64 contiguous bytes per lane.
+//   tn: C[p][q] = sum_t U[t][p] V[t][q]      both operands contiguous along the OUTPUT index
+//       (weight gradients: contraction over tokens).  LDS image [64 t][128 cols] (256-B rows),
+//       fragments come out transposed through ds_read_b64_tr_b16.  Split over t into
+//       blockIdx.z slabs (fp32) that a second kernel sums in slab order (deterministic).
+//
+// Out-of-range rows/chunks are fetched from a 16-byte zero word instead of being clamped, so
+// ragged M, N, K contribute exact zeros.
+#include "common.h"
+
+namespace {
+
+constexpr int TM = 128, TN_ = 128, TK = 64;
+constexpr int NT = 256;
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_dst, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// nt kernel
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz_nt(int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); }
+
+// stage one [128 rows][64 k] tile: wave w issues 4 loads, load i covers rows (4w+i)*8 .. +7
+__device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ g, long long ld, int row0, int rows, int k0, int K,
+                                         bf16_t* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rblk = (wave * 4 + i) * 8;
+        const int r = rblk + (lane >> 3);
+        const int c = (lane & 7) ^ swz_nt(r);      // logical chunk this lane fetches
+        const int gr = row0 + r, gk = k0 + c * 8;
+        const void* src = (gr < rows && gk < K) ? (const void*)(g + (long long)gr * ld + gk) : (const void*)g_zero16;
+        glds16(src, lds + rblk * TK);
+    }
+}
+
+__device__ __forceinline__ bf16x8 frag_nt(const bf16_t* lds, int row, int chunk) {
+    return *reinterpret_cast<const bf16x8*>(lds + row * TK + ((chunk ^ swz_nt(row)) << 3));
+}
+
+struct FastEpi {
+    void* C;
+    long long ldc;
+    const float* bias;
+    const bf16_t* res;
+    long long ldr;
+    bf16_t* aux;
+    long long ldaux;
+};
+
+template <int EPI, typename OutT>
+__device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N, float (&v)[16]) {
+    // v[t] belongs to column n + t of row m
+    const bool full = (n + 16 <= N);
+    if (e.bias) {
+        if (full) {
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + n + 4 * t4);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[4 * t4 + t] += b[t];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (n + t < N) v[t] += e.bias[n + t];
+        }
+    }
+    if (EPI == VITMI_EPI_GELU) {
+        if (e.aux) {
+            bf16_t* a = e.aux + (long long)m * e.ldaux + n;
+            if (full) {
+                bf16x8 p0, p1;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    p0[t] = (bf16_t)v[t];
+                    p1[t] = (bf16_t)v[8 + t];
+                }
+                *reinterpret_cast<bf16x8*>(a) = p0;
+                *reinterpret_cast<bf16x8*>(a + 8) = p1;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+                    if (n + t < N) a[t] = (bf16_t)v[t];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = gelu_erf(v[t]);
+    } else if (EPI == VITMI_EPI_DGELU) {
+        const bf16_t* a = e.aux + (long long)m * e.ldaux + n;
+        if (full) {
+            const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a);
+            const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a + 8);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                v[t] *= gelu_erf_grad((float)p0[t]);
+                v[8 + t] *= gelu_erf_grad((float)p1[t]);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (n + t < N) v[t] *= gelu_erf_grad((float)a[t]);
+        }
+    }
+    if (e.res) {
+        const bf16_t* r = e.res + (long long)m * e.ldr + n;
+        if (full) {
+            const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(r);
+            const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(r + 8);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                v[t] += (float)p0[t];
+                v[8 + t] += (float)p1[t];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (n + t < N) v[t] += (float)r[t];
+        }
+    }
+    OutT* c = reinterpret_cast<OutT*>(e.C) + (long long)m * e.ldc + n;
+    if (full) {
+        if (sizeof(OutT) == 2) {
+            bf16x8 p0, p1;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                p0[t] = (bf16_t)v[t];
+                p1[t] = (bf16_t)v[8 + t];
+            }
+            *reinterpret_cast<bf16x8*>(c) = p0;
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(c) + 8) = p1;
+        } else {
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4)
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(c) + 4 * t4) =
+                    f32x4{v[4 * t4], v[4 * t4 + 1], v[4 * t4 + 2], v[4 * t4 + 3]};
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (n + t < N) c[t] = from_f32<OutT>(v[t]);
+    }
+}
+
+// XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous
+// run of tiles; within a run the n-tile index moves fastest (neighbours share the A row panel).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int x = bid & 7, l = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+}
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(NT) void gemm_nt_fast_kernel(const bf16_t* __restrict__ A, long long lda,
+                                                          const bf16_t* __restrict__ B, long long ldb, FastEpi epi,
+                                                          int M, int N, int K, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (TM + TN_) * TK];  // 64 KiB: A0 B0 A1 B1
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN_;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    f32x4 acc[4][4];  // [j: n-tile][i: m-tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (K + TK - 1) / TK;
+    stage_nt(A, lda, m0, M, 0, K, smem, wave, lane);
+    stage_nt(B, ldb, n0, N, 0, K, smem + TM * TK, wave, lane);
+    __syncthreads();
+    // weight rows of n-tile j in the order that leaves n = 16*fg + 4*j + r in accumulator register r
+    int wrow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wrow[j] = wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        bf16_t* As = smem + (kt & 1) * (TM + TN_) * TK;
+        bf16_t* Bs = As + TM * TK;
+        if (kt + 1 < nk) {
+            bf16_t* An = smem + ((kt + 1) & 1) * (TM + TN_) * TK;
+            stage_nt(A, lda, m0, M, (kt + 1) * TK, K, An, wave, lane);
+            stage_nt(B, ldb, n0, N, (kt + 1) * TK, K, An + TM * TK, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < TK / 32; ++ks) {
+            bf16x8 fw[4], fx[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fw[j] = frag_nt(Bs, wrow[j], ks * 4 + fg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fx[i] = frag_nt(As, wm * 64 + i * 16 + fr, ks * 4 + fg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fx[i], acc[j][i], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        const int n = n0 + wn * 64 + 16 * fg;
+        if (m < M && n < N) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[j][i][r];
+            epi_row16<EPI, OutT>(epi, m, n, N, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tn kernel (weight gradients)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz_tn(int t) { return ((t & 3) | (((t >> 3) & 1) << 2)) << 1; }
+
+// stage one [64 t][128 cols] tile (256-B rows): wave w issues 4 loads, load i covers t = (4w+i)*4 .. +3
+__device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ g, long long ld, int t0, int T, int col0, int cols,
+                                         bf16_t* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tblk = (wave * 4 + i) * 4;
+        const int t = tblk + (lane >> 4);
+        const int c = (lane & 15) ^ swz_tn(t);
+        const int gt = t0 + t, gc = col0 + c * 8;
+        const void* src = (gt < T && gc < cols) ? (const void*)(g + (long long)gt * ld + gc) : (const void*)g_zero16;
+        glds16(src, lds + tblk * 128);
+    }
+}
+
+// fragment for 16 consecutive columns col0..col0+15, k-step ks (32 t): element j of lane (fr,fg)
+// = tile[t = 32 ks + 8 fg + j][col0 + fr]
+__device__ __forceinline__ bf16x8 frag_tn(const bf16_t* lds, int col0, int ks, int lane) {
+    const int fg = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int col = col0 + 4 * p;              // 4 consecutive columns, 8 bytes
+    const int t_lo = 32 * ks + 8 * fg + q, t_hi = t_lo + 4;
+    const int o_lo = t_lo * 128 + ((((col >> 3) ^ swz_tn(t_lo)) << 3) | (col & 7));
+    const int o_hi = t_hi * 128 + ((((col >> 3) ^ swz_tn(t_hi)) << 3) | (col & 7));
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + o_lo));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + o_hi));
+    union {
+        s16x4 h[2];
+        bf16x8 v;
+    } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+}
+
+__global__ __launch_bounds__(NT) void gemm_tn_fast_kernel(const bf16_t* __restrict__ U, long long ldu,
+                                                          const bf16_t* __restrict__ V, long long ldv,
+                                                          float* __restrict__ C, long long ldc, long long slab_stride,
+                                                          int P, int Q, int T, int tiles_q, int kt_per_slab) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * TK * 128];  // 64 KiB: U0 V0 U1 V1
+    const int tile = blockIdx.x;
+    const int p0 = (tile / tiles_q) * 128, q0 = (tile % tiles_q) * 128;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wp = wave >> 1, wq = wave & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nk_all = (T + TK - 1) / TK;
+    const int kt_begin = blockIdx.z * kt_per_slab;
+    const int kt_end = min(kt_begin + kt_per_slab, nk_all);
+
+    f32x4 acc[4][4];  // [j: q-tile][i: p-tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (kt_begin < kt_end) {
+        stage_tn(U, ldu, kt_begin * TK, T, p0, P, smem, wave, lane);
+        stage_tn(V, ldv, kt_begin * TK, T, q0, Q, smem + TK * 128, wave, lane);
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int b = (kt - kt_begin) & 1;
+        bf16_t* Us = smem + b * 2 * TK * 128;
+        bf16_t* Vs = Us + TK * 128;
+        if (kt + 1 < kt_end) {
+            bf16_t* Un = smem + (b ^ 1) * 2 * TK * 128;
+            stage_tn(U, ldu, (kt + 1) * TK, T, p0, P, Un, wave, lane);
+            stage_tn(V, ldv, (kt + 1) * TK, T, q0, Q, Un + TK * 128, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < TK / 32; ++ks) {
+            bf16x8 fv[4], fu[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fv[j] = frag_tn(Vs, wq * 64 + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fu[i] = frag_tn(Us, wp * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[j], fu[i], acc[j][i], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // acc[j][i][r] = C[p = p0 + wp*64 + i*16 + fr][q = q0 + wq*64 + j*16 + 4*fg + r]
+    float* out = C + (long long)blockIdx.z * slab_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + wp * 64 + i * 16 + fr;
+        if (p >= P) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + wq * 64 + j * 16 + 4 * fg;
+            if (q + 4 <= Q) {
+                *reinterpret_cast<f32x4*>(out + (long long)p * ldc + q) = acc[j][i];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (q + r < Q) out[(long long)p * ldc + q + r] = acc[j][i][r];
+            }
+        }
+    }
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int nslabs,
+                                   float* __restrict__ out, long long n4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(slabs + 4 * i);
+        for (int k = 1; k < nslabs; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + k * slab_stride + 4 * i);
+            s += v;
+        }
+        *reinterpret_cast<f32x4*>(out + 4 * i) = s;
+    }
+}
+
+// out[c][r] (bf16) = in[r][c] (fp32 or bf16): transposed compute copies of the weights
+template <typename S>
+__global__ void transpose_cast_kernel(const S* __restrict__ in, bf16_t* __restrict__ out, int R, int Cn) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < Cn) ? to_f32(in[(long long)r * Cn + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < Cn && r < R) out[(long long)c * R + r] = (bf16_t)tile[tx][k];
+    }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+// true when the nt fast path can take the problem
+bool vitmi_gemm_nt_fast_ok(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
+                           const void* C, long long ldc, int c_dt, const void* res, long long ldr, const void* aux,
+                           long long ldaux) {
+    (void)M;
+    (void)N;
+    if (K % 8 || lda % 8 || ldb % 8 || !al16(A) || !al16(B) || !al16(C)) return false;
+    if (ldc % (c_dt == VITMI_F32 ? 4 : 8)) return false;
+    if (res && (ldr % 8 || !al16(res))) return false;
+    if (aux && (ldaux % 8 || !al16(aux))) return false;
+    return true;
+}
+
+int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
+                       long long ldc, int c_dt, int epilogue, const float* bias, const void* residual, long long ldr,
+                       void* aux, long long ldaux, hipStream_t s) {
+    FastEpi e{C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)aux, ldaux};
+    const int tiles_m = ceil_div(M, TM), tiles_n = ceil_div(N, TN_);
+    dim3 grid(tiles_m * tiles_n), block(NT);
+    const bf16_t* a = (const bf16_t*)A;
+    const bf16_t* b = (const bf16_t*)B;
+    if (c_dt == VITMI_F32)
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_NONE, float>), grid, block, 0, s, a, lda, b, ldb, e, M, N, K,
+                           tiles_n);
+    else if (epilogue == VITMI_EPI_NONE)
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_NONE, bf16_t>), grid, block, 0, s, a, lda, b, ldb, e, M, N, K,
+                           tiles_n);
+    else if (epilogue == VITMI_EPI_GELU)
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_GELU, bf16_t>), grid, block, 0, s, a, lda, b, ldb, e, M, N, K,
+                           tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_DGELU, bf16_t>), grid, block, 0, s, a, lda, b, ldb, e, M, N,
+                           K, tiles_n);
+    VITMI_LAUNCH_CHECK("vitmi_gemm(nt fast)");
+    return VITMI_OK;
+}
+
+bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const void* V, long long ldv, const void* C,
+                           long long ldc) {
+    return !(P % 8 || Q % 8 || ldu % 8 || ldv % 8 || ldc % 4 || !al16(U) || !al16(V) || !al16(C));
+}
+
+// number of t-slabs the tn kernel would use (the caller sizes the workspace from it)
+int vitmi_gemm_tn_slabs(int P, int Q, int T) {
+    const int tiles = ceil_div(P, 128) * ceil_div(Q, 128);
+    const int nk = ceil_div(T, TK);
+    int s = (512 + tiles - 1) / tiles;  // aim at ~2 resident blocks per CU on 256 CUs
+    if (s > nk) s = nk;
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return s;
+}
+
+int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
+                       long long ldc, float* slabs, hipStream_t s) {
+    const int tiles_p = ceil_div(P, 128), tiles_q = ceil_div(Q, 128);
+    int ns = vitmi_gemm_tn_slabs(P, Q, T);
+    if (!slabs) ns = 1;
+    const int nk = ceil_div(T, TK);
+    const int per = ceil_div(nk, ns);
+    ns = ceil_div(nk, per);
+    dim3 grid(tiles_p * tiles_q, 1, ns), block(NT);
+    if (ns == 1) {
+        hipLaunchKernelGGL(gemm_tn_fast_kernel, grid, block, 0, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv, C,
+                           ldc, 0ll, P, Q, T, tiles_q, per);
+        VITMI_LAUNCH_CHECK("vitmi_gemm(tn fast)");
+        return VITMI_OK;
+    }
+    // slabs are dense [ns][P][Q']: Q' = ldc so that the reduce is a flat sum when C is dense
+    const long long slab_stride = (long long)P * ldc;
+    hipLaunchKernelGGL(gemm_tn_fast_kernel, grid, block, 0, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv, slabs,
+                       ldc, slab_stride, P, Q, T, tiles_q, per);
+    VITMI_LAUNCH_CHECK("vitmi_gemm(tn fast)");
+    const long long n4 = slab_stride / 4;
+    int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, slab_stride, ns, C, n4);
+    VITMI_LAUNCH_CHECK("vitmi_gemm(tn reduce)");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_transpose_cast(const void* src, int src_dt, void* dst, int rows, int cols, void* stream) {
+    VITMI_CHECK_ARG(src && dst && rows > 0 && cols > 0, "vitmi_transpose_cast: bad argument");
+    hipStream_t s = as_stream(stream);
+    dim3 grid(ceil_div(cols, 32), ceil_div(rows, 32)), block(256);
+    if (src_dt == VITMI_F32)
+        hipLaunchKernelGGL(transpose_cast_kernel<float>, grid, block, 0, s, (const float*)src, (bf16_t*)dst, rows, cols);
+    else if (src_dt == VITMI_BF16)
+        hipLaunchKernelGGL(transpose_cast_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)src, (bf16_t*)dst, rows,
+                           cols);
+    else {
+        vitmi_set_error("vitmi_transpose_cast: bad dtype %d", src_dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    VITMI_LAUNCH_CHECK("vitmi_transpose_cast");
+    return VITMI_OK;
+}

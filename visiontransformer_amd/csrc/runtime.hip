@@ -125,10 +125,15 @@ extern "C" const char* vitmi_prof_name(int family) {
     static const char* epi[] = {"plain->bf16", "plain->f32", "gelu->bf16", "dgelu->bf16"};
     static thread_local char buf[128];
     if (family >= 0 && family < VITMI_FAM_GEMM_VARIANT0) return fixed[family];
-    if (family >= VITMI_FAM_GEMM_VARIANT0 && family < VITMI_FAM_COUNT) {
+    if (family >= VITMI_FAM_GEMM_VARIANT0 && family < VITMI_FAM_GEMM_NT_FAST0) {
         const int v = family - VITMI_FAM_GEMM_VARIANT0;
         snprintf(buf, sizeof(buf), "gemm_bf16_kernel[%s, %s]", layout[v >> 2], epi[v & 3]);
         return buf;
     }
+    if (family >= VITMI_FAM_GEMM_NT_FAST0 && family < VITMI_FAM_GEMM_TN_FAST) {
+        snprintf(buf, sizeof(buf), "gemm_nt_fast_kernel[%s]", epi[family - VITMI_FAM_GEMM_NT_FAST0]);
+        return buf;
+    }
+    if (family == VITMI_FAM_GEMM_TN_FAST) return "gemm_tn_fast_kernel[+slab_reduce]";
     return "?";
 }

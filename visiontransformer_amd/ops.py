@@ -70,7 +70,26 @@ def compute_copy(param, dtype):
     return c
 
 
+def compute_copy_t(param, dtype):
+    """Transposed compute copy of a 2-D weight: [K, N] for a parameter stored [N, K].  bf16 only
+    (the fp32 kernels read the weight through strides instead)."""
+    key = (id(param), dtype, "T")
+    hit = _cast_cache.get(key)
+    ver = param._version
+    if hit is not None and hit[0] == ver and hit[1] == param.data_ptr() and hit[2].device == param.device:
+        return hit[2]
+    _need_gpu(param)
+    src = param.detach().contiguous()
+    n, k = src.shape
+    out = torch.empty((k, n), dtype=dtype, device=src.device)
+    check(lib.vitmi_transpose_cast(_p(src), _dt(src), _p(out), n, k, _stream()), "vitmi_transpose_cast")
+    _cast_cache[key] = (ver, param.data_ptr(), out)
+    return out
+
+
 def clear_cast_cache():
+    """Drop every cached compute copy (call after parameters were changed behind autograd's back,
+    e.g. by the fused optimizer kernel)."""
     _cast_cache.clear()
 
 
@@ -95,13 +114,18 @@ def linear_fwd(x2, w, bias=None, res=None, epi=EPI_NONE, want_aux=False, out_dty
     return y, aux
 
 
-def linear_bwd_x(dy2, w, epi=EPI_NONE, aux=None):
-    """dx[T,K] = dy2[T,N] @ w[N,K]   (optionally times gelu'(aux))."""
+def linear_bwd_x(dy2, w, epi=EPI_NONE, aux=None, w_t=None):
+    """dx[T,K] = dy2[T,N] @ w[N,K]   (optionally times gelu'(aux)).  With w_t = w^T stored [K,N]
+    the product runs in the k-contiguous form."""
     T, N = dy2.shape
-    K = w.shape[1]
+    K = w.shape[1] if w_t is None else w_t.shape[0]
     dx = torch.empty((T, K), dtype=dy2.dtype, device=dy2.device)
-    gemm_raw(_dt(dy2), T, K, N, dy2, dy2.stride(0), 1, w, 1, w.stride(0), dx, K, _dt(dx), epi, None, None, 0, aux,
-             K if aux is not None else 0)
+    if w_t is not None:
+        gemm_raw(_dt(dy2), T, K, N, dy2, dy2.stride(0), 1, w_t, w_t.stride(0), 1, dx, K, _dt(dx), epi, None, None, 0,
+                 aux, K if aux is not None else 0)
+    else:
+        gemm_raw(_dt(dy2), T, K, N, dy2, dy2.stride(0), 1, w, 1, w.stride(0), dx, K, _dt(dx), epi, None, None, 0, aux,
+                 K if aux is not None else 0)
     return dx
 
 
@@ -110,8 +134,16 @@ def linear_bwd_w(dy2, x2):
     T, N = dy2.shape
     K = x2.shape[1]
     dw = torch.empty((N, K), dtype=torch.float32, device=dy2.device)
-    gemm_raw(_dt(dy2), N, K, T, dy2, 1, dy2.stride(0), x2, 1, x2.stride(0), dw, K, F32)
+    dt = _dt(dy2)
+    ws = _ws(lib.vitmi_gemm_wgrad_workspace_bytes(dt, N, K, T), dy2.device)
+    check(lib.vitmi_gemm_wgrad(dt, N, K, T, _p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(dw), K, _p(ws),
+                               _stream()), "vitmi_gemm_wgrad")
     return dw
+
+
+def weight_t(param, cdt):
+    """Transposed bf16 copy for the input-gradient product, or None in fp32 mode."""
+    return compute_copy_t(param, cdt) if cdt == torch.bfloat16 else None
 
 
 def colsum(x2):
@@ -307,7 +339,7 @@ class LinearFn(torch.autograd.Function):
         if dy2.dtype != ctx.cdt:
             dy2 = cast(dy2, ctx.cdt)
         w_c = compute_copy(weight, ctx.cdt)
-        dx = linear_bwd_x(dy2, w_c).view(ctx.in_shape)
+        dx = linear_bwd_x(dy2, w_c, w_t=weight_t(weight, ctx.cdt)).view(ctx.in_shape)
         if dx.dtype != ctx.in_dtype:
             dx = cast(dx, ctx.in_dtype)
         dw = linear_bwd_w(dy2, x2).to(weight.dtype)
@@ -371,14 +403,14 @@ class AttnBlockFn(torch.autograd.Function):
             wo = compute_copy(w_out, cdt)
             dwo = linear_bwd_w(dy2, o2).to(w_out.dtype)
             dbo = colsum(dy2).to(w_out.dtype) if has_bo else None
-            do = linear_bwd_x(dy2, wo)
+            do = linear_bwd_x(dy2, wo, w_t=weight_t(w_out, cdt))
         else:
             do = dy2
         dqkv = attn_bwd(qkv, o, do.view(B, N, inner), lse, B, N, heads, dh)
         dqkv2 = dqkv.view(B * N, 3 * inner)
         wq = compute_copy(w_qkv, cdt)
         dwq = linear_bwd_w(dqkv2, xn).to(w_qkv.dtype)
-        dxn = linear_bwd_x(dqkv2, wq)
+        dxn = linear_bwd_x(dqkv2, wq, w_t=weight_t(w_qkv, cdt))
         dg = db = None
         if has_ln:
             dx, dg, db = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None)
@@ -424,10 +456,10 @@ class FFBlockFn(torch.autograd.Function):
             xn = x2
         dw2 = linear_bwd_w(dy2, h).to(w2.dtype)
         db2 = colsum(dy2).to(w2.dtype)
-        du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u)
+        du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u, w_t=weight_t(w2, cdt))
         dw1 = linear_bwd_w(du, xn).to(w1.dtype)
         db1 = colsum(du).to(w1.dtype)
-        dxn = linear_bwd_x(du, compute_copy(w1, cdt))
+        dxn = linear_bwd_x(du, compute_copy(w1, cdt), w_t=weight_t(w1, cdt))
         dg = db = None
         if has_ln:
             dx, dg, db = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None)

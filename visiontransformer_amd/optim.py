@@ -39,6 +39,8 @@ class FusedAdam:
             p16 = None
             if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
                 p16 = hit[2]
+            # the transposed copy cannot be refreshed in the same pass: drop it, it is rebuilt on use
+            ops._cast_cache.pop((id(p), torch.bfloat16, "T"), None)
             check(lib.vitmi_adam_step(p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
                                       p16.data_ptr() if p16 is not None else None, p.numel(), self.lr, self.betas[0],
                                       self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, stream),
