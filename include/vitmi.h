@@ -107,9 +107,11 @@ int vitmi_colsum(const void* x, int dt, long long rows, int cols, long long ld, 
  * written at out + b*out_batch_stride + j*D (dt), so it can land inside a [B,N,D] buffer.  */
 int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, const float* bias, void* out, int dt, int B, int C,
                           int H, int W, int p, int D, long long out_batch_stride, void* stream);
-/* dW[d, k] = sum_{b,j} dy[b,j,d] * patch(b,j)[k]  (fp32 [D, C*p*p]).  Conv2d weight gradient. */
-int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, long long dy_batch_stride, float* dw, int dt,
-                            int B, int C, int H, int W, int p, int D, void* stream);
+/* dW[d, k] = sum_{b,j} dy[b,j,d] * patch(b,j)[k]  (fp32 [D, C*p*p]).  Conv2d weight gradient.
+ * dy is dense [B, tokens, D]; workspace from the query below (may be 0 bytes -> NULL). */
+long long vitmi_patch_embed_bwd_w_workspace_bytes(int dt, int B, int C, int H, int W, int p, int D);
+int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, long long dy_batch_stride, float* dw,
+                            void* workspace, int dt, int B, int C, int H, int W, int p, int D, void* stream);
 
 /* Token assembly + positional embedding (mymodel/ViT.py:155-159; ViT_mask.py:156-172):
  *   out[b,0,:]   = cls[:]          + pe[row(0),:]

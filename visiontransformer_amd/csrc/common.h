@@ -73,6 +73,32 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one v_rcp, one v_exp and a 5-term
+// polynomial.  Used by the bf16 epilogues, where the result is rounded to 8 bits of mantissa;
+// the fp32 path keeps libm's erff.  Returns erf(x/sqrt2) and exp(-x^2/2) together because GELU
+// and its derivative need both.
+__device__ __forceinline__ void erf_exp_fast(float x, float& erf_v, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);  // exp(-x^2/2)
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float r = 1.0f - p * t * e;
+    erf_v = copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+    float er, e;
+    erf_exp_fast(x, er, e);
+    return 0.5f * x * (1.0f + er);
+}
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    float er, e;
+    erf_exp_fast(x, er, e);
+    return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
+}
+
 // exact-erf GELU and its derivative (nn.GELU() default form)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -113,12 +113,18 @@ __global__ void colsum_partial_kernel(const T* __restrict__ x, long long rows, i
     }
 }
 
+// out[c] = sum_k partial[k][c], k ascending: 64 columns x 4 row-groups per block, the groups'
+// partial sums combined through LDS in a fixed order
 __global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int k = 0; k < chunks; ++k) s += partial[(long long)k * cols + c];
-    out[c] = s;
+    if (c < cols)
+        for (int k = grp; k < chunks; k += 4) s += partial[(long long)k * cols + c];
+    __shared__ float red[4][64];
+    red[grp][lane] = s;
+    __syncthreads();
+    if (grp == 0 && c < cols) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
 inline int colsum_chunks(long long rows) {
@@ -144,7 +150,7 @@ int launch_colsum(const void* x, long long rows, int cols, long long ld, float* 
                            rows_per_chunk);
     }
     VITMI_LAUNCH_CHECK("vitmi_colsum(partial)");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, s, partial, chunks, cols, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, s, partial, chunks, cols, out);
     VITMI_LAUNCH_CHECK("vitmi_colsum(final)");
     return VITMI_OK;
 }
@@ -348,20 +354,27 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
 
 __global__ void layernorm_bwd_final_kernel(const float* __restrict__ partial, int blocks, int D,
                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= D) return;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float a = 0.f, b = 0.f;
-    for (int k = 0; k < blocks; ++k) {
-        a += partial[((long long)k * 2 + 0) * D + c];
-        b += partial[((long long)k * 2 + 1) * D + c];
+    if (c < D)
+        for (int k = grp; k < blocks; k += 4) {
+            a += partial[((long long)k * 2 + 0) * D + c];
+            b += partial[((long long)k * 2 + 1) * D + c];
+        }
+    __shared__ float red[2][4][64];
+    red[0][grp][lane] = a;
+    red[1][grp][lane] = b;
+    __syncthreads();
+    if (grp == 0 && c < D) {
+        if (dgamma) dgamma[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+        if (dbeta) dbeta[c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
     }
-    if (dgamma) dgamma[c] = a;
-    if (dbeta) dbeta[c] = b;
 }
 
 inline int ln_bwd_blocks(long long rows) {
     long long b = (rows + 3) / 4;
-    if (b > 512) b = 512;
+    if (b > 256) b = 256;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -626,7 +639,7 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx,
 #undef LN_BWD
     VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd");
     if (dgamma || dbeta) {
-        hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(ceil_div(D, 256)), dim3(256), 0, s, partial, blocks, D,
+        hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, s, partial, blocks, D,
                            dgamma, dbeta);
         VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd(final)");
     }

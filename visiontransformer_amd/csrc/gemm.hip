@@ -26,6 +26,12 @@ bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const voi
 int vitmi_gemm_tn_slabs(int P, int Q, int T);
 int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
                        long long ldc, float* slabs, hipStream_t s);
+bool vitmi_patch_fast_ok(const void* img, const void* w, const void* out, int W, int p, int D, int E,
+                         long long out_batch_stride);
+int vitmi_patch_fwd_fast(const void* img, const void* w, const float* bias, void* out, int B, int C, int H, int W,
+                         int p, int D, long long out_batch_stride, hipStream_t s);
+int vitmi_patch_bwd_w_fast(const void* img, const void* dy, float* dw, float* slabs, int B, int C, int H, int W, int p,
+                           int D, hipStream_t s);
 
 namespace {
 
@@ -417,6 +423,10 @@ extern "C" int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, con
     VITMI_CHECK_ARG(out_batch_stride >= (long long)per * D, "vitmi_patch_embed_fwd: out_batch_stride too small");
     hipStream_t s = as_stream(stream);
     Epilogue epi{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride};
+    if (dt == VITMI_BF16 && x_dt == VITMI_BF16 && vitmi_patch_fast_ok(x, w, out, W, p, D, K, out_batch_stride)) {
+        ProfScope prof(VITMI_FAM_GEMM_NT_FAST0, s, 2.0 * M * N * K);
+        return vitmi_patch_fwd_fast(x, w, bias, out, B, C, H, W, p, D, out_batch_stride, s);
+    }
     ProfScope prof(VITMI_FAM_GEMM, s, 2.0 * M * N * K);
     if (dt == VITMI_F32) {
         VITMI_CHECK_ARG(x_dt == VITMI_F32, "vitmi_patch_embed_fwd: fp32 compute needs an fp32 image");
@@ -443,8 +453,16 @@ extern "C" int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, con
     return VITMI_OK;
 }
 
+extern "C" long long vitmi_patch_embed_bwd_w_workspace_bytes(int dt, int B, int C, int H, int W, int p, int D) {
+    if (dt != VITMI_BF16 || p <= 0) return 0;
+    const int E = C * p * p, T = B * (H / p) * (W / p);
+    const int ns = vitmi_gemm_tn_slabs(D, E, T);
+    return ns > 1 ? (long long)ns * D * E * (long long)sizeof(float) : 0;
+}
+
 extern "C" int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, long long dy_batch_stride, float* dw,
-                                       int dt, int B, int C, int H, int W, int p, int D, void* stream) {
+                                       void* workspace, int dt, int B, int C, int H, int W, int p, int D,
+                                       void* stream) {
     VITMI_CHECK_ARG(x && dy && dw, "vitmi_patch_embed_bwd_w: null pointer");
     VITMI_CHECK_ARG(B > 0 && C > 0 && p > 0 && D > 0 && H > 0 && W > 0 && H % p == 0 && W % p == 0,
                     "vitmi_patch_embed_bwd_w: bad geometry");
@@ -456,6 +474,10 @@ extern "C" int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, 
     hipStream_t s = as_stream(stream);
     // dW[d, e] = sum_t dy[t, d] * P[t, e]:  rows of A = d (dy is contiguous along d), rows of B = e, k = t
     Epilogue epi{dw, E, nullptr, nullptr, 0, nullptr, 0, 0, 0};
+    if (dt == VITMI_BF16 && x_dt == VITMI_BF16 && vitmi_patch_fast_ok(x, dy, dw, W, p, D, E, 8)) {
+        ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * D * E * (double)T);
+        return vitmi_patch_bwd_w_fast(x, dy, dw, (float*)workspace, B, C, H, W, p, D, s);
+    }
     ProfScope prof(VITMI_FAM_GEMM, s, 2.0 * D * E * (double)T);
     if (dt == VITMI_F32) {
         VITMI_CHECK_ARG(x_dt == VITMI_F32, "vitmi_patch_embed_bwd_w: fp32 compute needs an fp32 image");

@@ -53,6 +53,35 @@ __device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ g, long long
     }
 }
 
+// Patch operand: logical matrix P[token m][element e], m = (image b, gy, gx), e = (c, i, j), read in
+// place from the NCHW image: P = x[b, c, gy*ps + i, gx*ps + j].  With ps % 8 == 0 a 16-byte chunk
+// (8 elements) never leaves one patch row, so it is 16 contiguous bytes of the image.
+struct PatchGeom {
+    int C, H, W, ps, gw, per;  // per = patches per image
+    int tokens, elems;         // B*per, C*ps*ps
+};
+__device__ __forceinline__ long long patch_addr(const PatchGeom& g, int m, int e) {
+    const int b = m / g.per, t = m - b * g.per;
+    const int gy = t / g.gw, gx = t - gy * g.gw;
+    const int c = e / (g.ps * g.ps), q = e - c * g.ps * g.ps;
+    const int i = q / g.ps, j = q - i * g.ps;
+    return (((long long)b * g.C + c) * g.H + (gy * g.ps + i)) * g.W + gx * g.ps + j;
+}
+
+__device__ __forceinline__ void stage_nt_patch(const bf16_t* __restrict__ img, const PatchGeom& pg, int row0, int k0,
+                                               bf16_t* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rblk = (wave * 4 + i) * 8;
+        const int r = rblk + (lane >> 3);
+        const int c = (lane & 7) ^ swz_nt(r);
+        const int gr = row0 + r, gk = k0 + c * 8;
+        const void* src = (gr < pg.tokens && gk < pg.elems) ? (const void*)(img + patch_addr(pg, gr, gk))
+                                                            : (const void*)g_zero16;
+        glds16(src, lds + rblk * TK);
+    }
+}
+
 __device__ __forceinline__ bf16x8 frag_nt(const bf16_t* lds, int row, int chunk) {
     return *reinterpret_cast<const bf16x8*>(lds + row * TK + ((chunk ^ swz_nt(row)) << 3));
 }
@@ -65,6 +94,8 @@ struct FastEpi {
     long long ldr;
     bf16_t* aux;
     long long ldaux;
+    int rows_per_group;      // > 0: row m lives at C + (m / rpg) * group_stride + (m % rpg) * ldc
+    long long group_stride;
 };
 
 template <int EPI, typename OutT>
@@ -104,7 +135,7 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
             }
         }
 #pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = gelu_erf(v[t]);
+        for (int t = 0; t < 16; ++t) v[t] = gelu_fast(v[t]);
     } else if (EPI == VITMI_EPI_DGELU) {
         const bf16_t* a = e.aux + (long long)m * e.ldaux + n;
         if (full) {
@@ -112,13 +143,13 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
             const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a + 8);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                v[t] *= gelu_erf_grad((float)p0[t]);
-                v[8 + t] *= gelu_erf_grad((float)p1[t]);
+                v[t] *= gelu_grad_fast((float)p0[t]);
+                v[8 + t] *= gelu_grad_fast((float)p1[t]);
             }
         } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t)
-                if (n + t < N) v[t] *= gelu_erf_grad((float)a[t]);
+                if (n + t < N) v[t] *= gelu_grad_fast((float)a[t]);
         }
     }
     if (e.res) {
@@ -138,6 +169,11 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
         }
     }
     OutT* c = reinterpret_cast<OutT*>(e.C) + (long long)m * e.ldc + n;
+    if (e.rows_per_group > 0) {
+        const int gi = m / e.rows_per_group;
+        c = reinterpret_cast<OutT*>(e.C) + (long long)gi * e.group_stride +
+            (long long)(m - gi * e.rows_per_group) * e.ldc + n;
+    }
     if (full) {
         if (sizeof(OutT) == 2) {
             bf16x8 p0, p1;
@@ -169,10 +205,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
 }
 
-template <int EPI, typename OutT>
+template <int EPI, typename OutT, bool PATCH>
 __global__ __launch_bounds__(NT) void gemm_nt_fast_kernel(const bf16_t* __restrict__ A, long long lda,
                                                           const bf16_t* __restrict__ B, long long ldb, FastEpi epi,
-                                                          int M, int N, int K, int tiles_n) {
+                                                          int M, int N, int K, int tiles_n, PatchGeom pg) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (TM + TN_) * TK];  // 64 KiB: A0 B0 A1 B1
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN_;
@@ -188,7 +224,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_fast_kernel(const bf16_t* __restri
         for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (K + TK - 1) / TK;
-    stage_nt(A, lda, m0, M, 0, K, smem, wave, lane);
+    if (PATCH)
+        stage_nt_patch(A, pg, m0, 0, smem, wave, lane);
+    else
+        stage_nt(A, lda, m0, M, 0, K, smem, wave, lane);
     stage_nt(B, ldb, n0, N, 0, K, smem + TM * TK, wave, lane);
     __syncthreads();
     // weight rows of n-tile j in the order that leaves n = 16*fg + 4*j + r in accumulator register r
@@ -201,7 +240,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_fast_kernel(const bf16_t* __restri
         bf16_t* Bs = As + TM * TK;
         if (kt + 1 < nk) {
             bf16_t* An = smem + ((kt + 1) & 1) * (TM + TN_) * TK;
-            stage_nt(A, lda, m0, M, (kt + 1) * TK, K, An, wave, lane);
+            if (PATCH)
+                stage_nt_patch(A, pg, m0, (kt + 1) * TK, An, wave, lane);
+            else
+                stage_nt(A, lda, m0, M, (kt + 1) * TK, K, An, wave, lane);
             stage_nt(B, ldb, n0, N, (kt + 1) * TK, K, An + TM * TK, wave, lane);
         }
 #pragma unroll
@@ -253,6 +295,20 @@ __device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ g, long long
     }
 }
 
+__device__ __forceinline__ void stage_tn_patch(const bf16_t* __restrict__ img, const PatchGeom& pg, int t0, int col0,
+                                               bf16_t* lds, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tblk = (wave * 4 + i) * 4;
+        const int t = tblk + (lane >> 4);
+        const int c = (lane & 15) ^ swz_tn(t);
+        const int gt = t0 + t, gc = col0 + c * 8;
+        const void* src = (gt < pg.tokens && gc < pg.elems) ? (const void*)(img + patch_addr(pg, gt, gc))
+                                                            : (const void*)g_zero16;
+        glds16(src, lds + tblk * 128);
+    }
+}
+
 // fragment for 16 consecutive columns col0..col0+15, k-step ks (32 t): element j of lane (fr,fg)
 // = tile[t = 32 ks + 8 fg + j][col0 + fr]
 __device__ __forceinline__ bf16x8 frag_tn(const bf16_t* lds, int col0, int ks, int lane) {
@@ -273,10 +329,12 @@ __device__ __forceinline__ bf16x8 frag_tn(const bf16_t* lds, int col0, int ks, i
     return u.v;
 }
 
+template <bool PATCH>
 __global__ __launch_bounds__(NT) void gemm_tn_fast_kernel(const bf16_t* __restrict__ U, long long ldu,
                                                           const bf16_t* __restrict__ V, long long ldv,
                                                           float* __restrict__ C, long long ldc, long long slab_stride,
-                                                          int P, int Q, int T, int tiles_q, int kt_per_slab) {
+                                                          int P, int Q, int T, int tiles_q, int kt_per_slab,
+                                                          PatchGeom pg) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * TK * 128];  // 64 KiB: U0 V0 U1 V1
     const int tile = blockIdx.x;
     const int p0 = (tile / tiles_q) * 128, q0 = (tile % tiles_q) * 128;
@@ -296,7 +354,10 @@ __global__ __launch_bounds__(NT) void gemm_tn_fast_kernel(const bf16_t* __restri
 
     if (kt_begin < kt_end) {
         stage_tn(U, ldu, kt_begin * TK, T, p0, P, smem, wave, lane);
-        stage_tn(V, ldv, kt_begin * TK, T, q0, Q, smem + TK * 128, wave, lane);
+        if (PATCH)
+            stage_tn_patch(V, pg, kt_begin * TK, q0, smem + TK * 128, wave, lane);
+        else
+            stage_tn(V, ldv, kt_begin * TK, T, q0, Q, smem + TK * 128, wave, lane);
     }
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -306,7 +367,10 @@ __global__ __launch_bounds__(NT) void gemm_tn_fast_kernel(const bf16_t* __restri
         if (kt + 1 < kt_end) {
             bf16_t* Un = smem + (b ^ 1) * 2 * TK * 128;
             stage_tn(U, ldu, (kt + 1) * TK, T, p0, P, Un, wave, lane);
-            stage_tn(V, ldv, (kt + 1) * TK, T, q0, Q, Un + TK * 128, wave, lane);
+            if (PATCH)
+                stage_tn_patch(V, pg, (kt + 1) * TK, q0, Un + TK * 128, wave, lane);
+            else
+                stage_tn(V, ldv, (kt + 1) * TK, T, q0, Q, Un + TK * 128, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < TK / 32; ++ks) {
@@ -391,28 +455,50 @@ bool vitmi_gemm_nt_fast_ok(int M, int N, int K, const void* A, long long lda, co
     return true;
 }
 
-int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
-                       long long ldc, int c_dt, int epilogue, const float* bias, const void* residual, long long ldr,
-                       void* aux, long long ldaux, hipStream_t s) {
-    FastEpi e{C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)aux, ldaux};
+template <bool PATCH>
+static int launch_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
+                          const FastEpi& e, int c_dt, int epilogue, const PatchGeom& pg, hipStream_t s) {
     const int tiles_m = ceil_div(M, TM), tiles_n = ceil_div(N, TN_);
     dim3 grid(tiles_m * tiles_n), block(NT);
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* b = (const bf16_t*)B;
     if (c_dt == VITMI_F32)
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_NONE, float>), grid, block, 0, s, a, lda, b, ldb, e, M, N, K,
-                           tiles_n);
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_NONE, float, PATCH>), grid, block, 0, s, a, lda, b, ldb, e, M,
+                           N, K, tiles_n, pg);
     else if (epilogue == VITMI_EPI_NONE)
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_NONE, bf16_t>), grid, block, 0, s, a, lda, b, ldb, e, M, N, K,
-                           tiles_n);
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_NONE, bf16_t, PATCH>), grid, block, 0, s, a, lda, b, ldb, e,
+                           M, N, K, tiles_n, pg);
     else if (epilogue == VITMI_EPI_GELU)
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_GELU, bf16_t>), grid, block, 0, s, a, lda, b, ldb, e, M, N, K,
-                           tiles_n);
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_GELU, bf16_t, PATCH>), grid, block, 0, s, a, lda, b, ldb, e,
+                           M, N, K, tiles_n, pg);
     else
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_DGELU, bf16_t>), grid, block, 0, s, a, lda, b, ldb, e, M, N,
-                           K, tiles_n);
+        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_DGELU, bf16_t, PATCH>), grid, block, 0, s, a, lda, b, ldb, e,
+                           M, N, K, tiles_n, pg);
     VITMI_LAUNCH_CHECK("vitmi_gemm(nt fast)");
     return VITMI_OK;
+}
+
+int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
+                       long long ldc, int c_dt, int epilogue, const float* bias, const void* residual, long long ldr,
+                       void* aux, long long ldaux, hipStream_t s) {
+    FastEpi e{C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)aux, ldaux, 0, 0};
+    return launch_nt_fast<false>(M, N, K, A, lda, B, ldb, e, c_dt, epilogue, PatchGeom{}, s);
+}
+
+// patch-embedding forward on a bf16 image: tokens x D = patches x W^T, rows land at
+// out + b*out_batch_stride + j*D
+bool vitmi_patch_fast_ok(const void* img, const void* w, const void* out, int W, int p, int D, int E,
+                         long long out_batch_stride) {
+    return p % 8 == 0 && W % 8 == 0 && D % 8 == 0 && E % 8 == 0 && out_batch_stride % 8 == 0 && al16(img) &&
+           al16(w) && al16(out);
+}
+
+int vitmi_patch_fwd_fast(const void* img, const void* w, const float* bias, void* out, int B, int C, int H, int W,
+                         int p, int D, long long out_batch_stride, hipStream_t s) {
+    const int gh = H / p, gw = W / p, per = gh * gw, E = C * p * p;
+    PatchGeom pg{C, H, W, p, gw, per, B * per, E};
+    FastEpi e{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride};
+    return launch_nt_fast<true>(B * per, D, E, img, 0, w, E, e, VITMI_BF16, VITMI_EPI_NONE, pg, s);
 }
 
 bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const void* V, long long ldv, const void* C,
@@ -431,8 +517,9 @@ int vitmi_gemm_tn_slabs(int P, int Q, int T) {
     return s;
 }
 
-int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
-                       long long ldc, float* slabs, hipStream_t s) {
+template <bool PATCH>
+static int launch_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
+                          long long ldc, float* slabs, const PatchGeom& pg, hipStream_t s) {
     const int tiles_p = ceil_div(P, 128), tiles_q = ceil_div(Q, 128);
     int ns = vitmi_gemm_tn_slabs(P, Q, T);
     if (!slabs) ns = 1;
@@ -441,21 +528,34 @@ int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const 
     ns = ceil_div(nk, per);
     dim3 grid(tiles_p * tiles_q, 1, ns), block(NT);
     if (ns == 1) {
-        hipLaunchKernelGGL(gemm_tn_fast_kernel, grid, block, 0, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv, C,
-                           ldc, 0ll, P, Q, T, tiles_q, per);
+        hipLaunchKernelGGL(gemm_tn_fast_kernel<PATCH>, grid, block, 0, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
+                           C, ldc, 0ll, P, Q, T, tiles_q, per, pg);
         VITMI_LAUNCH_CHECK("vitmi_gemm(tn fast)");
         return VITMI_OK;
     }
-    // slabs are dense [ns][P][Q']: Q' = ldc so that the reduce is a flat sum when C is dense
+    // slabs are dense [ns][P][ldc] so that the reduce is a flat sum when C is dense
     const long long slab_stride = (long long)P * ldc;
-    hipLaunchKernelGGL(gemm_tn_fast_kernel, grid, block, 0, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv, slabs,
-                       ldc, slab_stride, P, Q, T, tiles_q, per);
+    hipLaunchKernelGGL(gemm_tn_fast_kernel<PATCH>, grid, block, 0, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
+                       slabs, ldc, slab_stride, P, Q, T, tiles_q, per, pg);
     VITMI_LAUNCH_CHECK("vitmi_gemm(tn fast)");
     const long long n4 = slab_stride / 4;
     int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, slab_stride, ns, C, n4);
     VITMI_LAUNCH_CHECK("vitmi_gemm(tn reduce)");
     return VITMI_OK;
+}
+
+int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
+                       long long ldc, float* slabs, hipStream_t s) {
+    return launch_tn_fast<false>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, PatchGeom{}, s);
+}
+
+// patch-embedding weight gradient on a bf16 image: dW[d][e] = sum_t dy[t][d] * P[t][e]
+int vitmi_patch_bwd_w_fast(const void* img, const void* dy, float* dw, float* slabs, int B, int C, int H, int W, int p,
+                           int D, hipStream_t s) {
+    const int gh = H / p, gw = W / p, per = gh * gw, E = C * p * p;
+    PatchGeom pg{C, H, W, p, gw, per, B * per, E};
+    return launch_tn_fast<true>(D, E, B * per, dy, D, img, 0, dw, E, slabs, pg, s);
 }
 
 extern "C" int vitmi_transpose_cast(const void* src, int src_dt, void* dst, int rows, int cols, void* stream) {

@@ -226,6 +226,13 @@ class PatchEmbedFn(torch.autograd.Function):
         if cdt == torch.float32 and x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
+        if cdt == torch.bfloat16 and x.dtype != torch.bfloat16 and p % 8 == 0 and W % 8 == 0:
+            # one elementwise pass; the direct-to-LDS patch gather then reads 16-byte bf16 chunks
+            # of the image in place (forward and weight gradient), and the saved copy is half the size
+            ctx.x_dtype = x.dtype
+            x = cast(x, torch.bfloat16)
+        else:
+            ctx.x_dtype = x.dtype
         w_c = compute_copy(weight, cdt).view(D, C * p * p)
         out = torch.empty((B, per, D), dtype=cdt, device=x.device)
         bias_f = bias.detach().float() if bias is not None else None
@@ -244,7 +251,8 @@ class PatchEmbedFn(torch.autograd.Function):
         per = (H // p) * (W // p)
         dy = dy.contiguous()
         dw = torch.empty((D, C * p * p), dtype=torch.float32, device=x.device)
-        check(lib.vitmi_patch_embed_bwd_w(_p(x), _dt(x), _p(dy), per * D, _p(dw), _dt(dy), B, C, H, W, p, D,
+        ws = _ws(lib.vitmi_patch_embed_bwd_w_workspace_bytes(_dt(dy), B, C, H, W, p, D), x.device)
+        check(lib.vitmi_patch_embed_bwd_w(_p(x), _dt(x), _p(dy), per * D, _p(dw), _p(ws), _dt(dy), B, C, H, W, p, D,
                                           _stream()), "vitmi_patch_embed_bwd_w")
         db = colsum(dy.view(B * per, D)) if ctx.has_bias else None
         dx = None
@@ -252,7 +260,7 @@ class PatchEmbedFn(torch.autograd.Function):
             w_c = compute_copy(weight, ctx.cdt).view(D, C * p * p)
             dpatch = linear_bwd_x(dy.view(B * per, D), w_c)          # [B*per, C*p*p]
             gh, gw = H // p, W // p
-            dx = dpatch.view(B, gh, gw, C, p, p).permute(0, 3, 1, 4, 2, 5).reshape(B, C, H, W).to(x.dtype)
+            dx = dpatch.view(B, gh, gw, C, p, p).permute(0, 3, 1, 4, 2, 5).reshape(B, C, H, W).to(ctx.x_dtype)
         return dx, dw.view_as(weight).to(weight.dtype), (db.to(weight.dtype) if db is not None else None), None
 
 
