@@ -90,6 +90,12 @@ long long vitmi_gemm_wgrad_workspace_bytes(int dt, int P, int Q, int T);
 int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv,
                      float* C, long long ldc, void* workspace, void* stream);
 
+/* Tuning hook: force the block-tile configuration of the aligned nt GEMM (0 = 128x128, 1 = 256x128,
+ * 2 = 256x256; -1 = automatic).  Process-wide; for benchmarking only. */
+int vitmi_debug_set_nt_config(int cfg);
+/* same for the weight-gradient (tn) GEMM: 0 = 128x128, 1 = 256x256, -1 = automatic */
+int vitmi_debug_set_tn_config(int cfg);
+
 /* dst[c][r] (bf16) = src[r][c] (src_dt): the transposed bf16 compute copy of a weight, which
  * turns the input-gradient product dX = dY W into the k-contiguous form of vitmi_gemm.  No
  * reference counterpart (aten reads W through strides). */

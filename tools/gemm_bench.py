@@ -27,7 +27,15 @@ def timeit(fn, iters=10):
 
 
 def main():
+    from visiontransformer_amd._lib import lib
     bf = torch.bfloat16
+    for cfg in (0, 1, -1):
+        lib.vitmi_debug_set_tn_config(cfg)
+        print(f"--- tn tile config {cfg} (0=128x128 1=256x256 -1=auto)")
+        run(bf, dw=True)
+
+
+def run(bf, dw):
     rows = []
     for name, N, K in [("qkv", 2304, 768), ("out", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]:
         x = torch.randn(T, K, device=DEV).to(bf)
@@ -47,8 +55,9 @@ def main():
             rows.append((f"{name} fwd nt+res", ms, fl / ms / 1e9))
         ms = timeit(lambda: ops.linear_bwd_x(dy, w, w_t=wt))
         rows.append((f"{name} dx  nt(w^T)", ms, fl / ms / 1e9))
-        ms = timeit(lambda: ops.linear_bwd_w(dy, x))
-        rows.append((f"{name} dw  tn", ms, fl / ms / 1e9))
+        if dw:
+            ms = timeit(lambda: ops.linear_bwd_w(dy, x))
+            rows.append((f"{name} dw  tn", ms, fl / ms / 1e9))
     for n, ms, tf in rows:
         print(f"{n:36s} {ms:8.3f} ms  {tf:8.1f} TFLOP/s")
 

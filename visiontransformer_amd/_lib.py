@@ -30,6 +30,8 @@ SIGNATURES = {
     "vitmi_gemm_wgrad_workspace_bytes": (L, [I, I, I, I]),
     "vitmi_gemm_wgrad": (I, [I, I, I, I, P, L, P, L, P, L, P, P]),
     "vitmi_transpose_cast": (I, [P, I, P, I, I, P]),
+    "vitmi_debug_set_nt_config": (I, [I]),
+    "vitmi_debug_set_tn_config": (I, [I]),
     "vitmi_colsum_workspace_bytes": (L, [L, I]),
     "vitmi_colsum": (I, [P, I, L, I, L, P, P, P]),
     "vitmi_patch_embed_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, L, P]),

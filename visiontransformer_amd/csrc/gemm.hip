@@ -364,7 +364,7 @@ extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long 
     VITMI_CHECK_ARG(epilogue != VITMI_EPI_DGELU || aux, "vitmi_gemm: dGELU epilogue needs aux");
     VITMI_CHECK_ARG(!residual || ldr >= N, "vitmi_gemm: ldr=%lld < N=%d", ldr, N);
     VITMI_CHECK_ARG(!aux || ldaux >= N, "vitmi_gemm: ldaux=%lld < N=%d", ldaux, N);
-    VITMI_CHECK_ARG(sam > 0 && sak > 0 && sbn > 0 && sbk > 0, "vitmi_gemm: strides must be positive");
+    VITMI_CHECK_ARG(sam >= 0 && sak >= 0 && sbn >= 0 && sbk >= 0, "vitmi_gemm: strides must not be negative");
     hipStream_t s = as_stream(stream);
     Epilogue epi{C, ldc, bias, residual, ldr, aux, ldaux, 0, 0};
     int fam = VITMI_FAM_GEMM;
@@ -513,7 +513,7 @@ extern "C" long long vitmi_gemm_wgrad_workspace_bytes(int dt, int P, int Q, int 
 extern "C" int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long long ldu, const void* V,
                                 long long ldv, float* C, long long ldc, void* workspace, void* stream) {
     VITMI_CHECK_ARG(U && V && C, "vitmi_gemm_wgrad: null operand");
-    VITMI_CHECK_ARG(P > 0 && Q > 0 && T > 0 && ldu >= P && ldv >= Q && ldc >= Q, "vitmi_gemm_wgrad: bad shape");
+    VITMI_CHECK_ARG(P > 0 && Q > 0 && T > 0 && ldu >= 0 && ldv >= 0 && ldc >= Q, "vitmi_gemm_wgrad: bad shape");
     hipStream_t s = as_stream(stream);
     if (dt == VITMI_BF16 && ldc == Q && vitmi_gemm_tn_fast_ok(P, Q, U, ldu, V, ldv, C, ldc)) {
         ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * P * Q * (double)T);

@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int TM = 128, TN_ = 128, TK = 64;
+constexpr int TK = 64;
 constexpr int NT = 256;
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
@@ -39,12 +39,14 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz_nt(int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); }
 
-// stage one [128 rows][64 k] tile: wave w issues 4 loads, load i covers rows (4w+i)*8 .. +7
+// stage one [ROWS][64 k] tile with NW waves: wave w issues ROWS/8/NW loads, each covering 8 rows
+template <int ROWS, int NW>
 __device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ g, long long ld, int row0, int rows, int k0, int K,
                                          bf16_t* lds, int wave, int lane) {
+    constexpr int PER = ROWS / 8 / NW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rblk = (wave * 4 + i) * 8;
+    for (int i = 0; i < PER; ++i) {
+        const int rblk = (wave * PER + i) * 8;
         const int r = rblk + (lane >> 3);
         const int c = (lane & 7) ^ swz_nt(r);      // logical chunk this lane fetches
         const int gr = row0 + r, gk = k0 + c * 8;
@@ -68,11 +70,13 @@ __device__ __forceinline__ long long patch_addr(const PatchGeom& g, int m, int e
     return (((long long)b * g.C + c) * g.H + (gy * g.ps + i)) * g.W + gx * g.ps + j;
 }
 
+template <int ROWS, int NW>
 __device__ __forceinline__ void stage_nt_patch(const bf16_t* __restrict__ img, const PatchGeom& pg, int row0, int k0,
                                                bf16_t* lds, int wave, int lane) {
+    constexpr int PER = ROWS / 8 / NW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rblk = (wave * 4 + i) * 8;
+    for (int i = 0; i < PER; ++i) {
+        const int rblk = (wave * PER + i) * 8;
         const int r = rblk + (lane >> 3);
         const int c = (lane & 7) ^ swz_nt(r);
         const int gr = row0 + r, gk = k0 + c * 8;
@@ -205,70 +209,81 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
 }
 
-template <int EPI, typename OutT, bool PATCH>
-__global__ __launch_bounds__(NT) void gemm_nt_fast_kernel(const bf16_t* __restrict__ A, long long lda,
-                                                          const bf16_t* __restrict__ B, long long ldb, FastEpi epi,
-                                                          int M, int N, int K, int tiles_n, PatchGeom pg) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (TM + TN_) * TK];  // 64 KiB: A0 B0 A1 B1
+// BM x BN block tile, WM x WN waves, each wave a (BM/WM) x 64 sub-tile; dynamic LDS holds two
+// stages of [BM + BN][64] bf16.
+template <int EPI, typename OutT, bool PATCH, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(const bf16_t* __restrict__ A, long long lda,
+                                                                    const bf16_t* __restrict__ B, long long ldb,
+                                                                    FastEpi epi, int M, int N, int K, int tiles_n,
+                                                                    PatchGeom pg) {
+    constexpr int NW = WM * WN, WTM = BM / WM, WTN = BN / WN, MI = WTM / 16, NJ = WTN / 16;
+    static_assert(NJ == 4, "a lane owns 16 consecutive n = 4 n-tiles");
+    constexpr int STAGE = (BM + BN) * TK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN_;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fg = lane >> 4;
 
-    f32x4 acc[4][4];  // [j: n-tile][i: m-tile]
+    f32x4 acc[NJ][MI];  // [j: n-tile][i: m-tile]
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (K + TK - 1) / TK;
-    if (PATCH)
-        stage_nt_patch(A, pg, m0, 0, smem, wave, lane);
-    else
-        stage_nt(A, lda, m0, M, 0, K, smem, wave, lane);
-    stage_nt(B, ldb, n0, N, 0, K, smem + TM * TK, wave, lane);
-    __syncthreads();
     // weight rows of n-tile j in the order that leaves n = 16*fg + 4*j + r in accumulator register r
-    int wrow[4];
+    int wrow[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wrow[j] = wn * 64 + 16 * (fr >> 2) + 4 * j + (fr & 3);
+    for (int j = 0; j < NJ; ++j) wrow[j] = wn * WTN + 16 * (fr >> 2) + 4 * j + (fr & 3);
 
+    // Two LDS stages, one barrier per 64-deep K-tile: the direct-to-LDS loads of tile kt+1 are issued
+    // before the MFMAs of tile kt and drained by the barrier's wait.  (A hand-pipelined variant with
+    // two register fragment sets measured 10-25 % slower: it spills and defeats hipcc's own
+    // interleave of ds_read and MFMA.)
+    if (PATCH)
+        stage_nt_patch<BM, NW>(A, pg, m0, 0, smem, wave, lane);
+    else
+        stage_nt<BM, NW>(A, lda, m0, M, 0, K, smem, wave, lane);
+    stage_nt<BN, NW>(B, ldb, n0, N, 0, K, smem + BM * TK, wave, lane);
+    __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        bf16_t* As = smem + (kt & 1) * (TM + TN_) * TK;
-        bf16_t* Bs = As + TM * TK;
+        bf16_t* As = smem + (kt & 1) * STAGE;
+        bf16_t* Bs = As + BM * TK;
         if (kt + 1 < nk) {
-            bf16_t* An = smem + ((kt + 1) & 1) * (TM + TN_) * TK;
+            bf16_t* An = smem + ((kt + 1) & 1) * STAGE;
             if (PATCH)
-                stage_nt_patch(A, pg, m0, (kt + 1) * TK, An, wave, lane);
+                stage_nt_patch<BM, NW>(A, pg, m0, (kt + 1) * TK, An, wave, lane);
             else
-                stage_nt(A, lda, m0, M, (kt + 1) * TK, K, An, wave, lane);
-            stage_nt(B, ldb, n0, N, (kt + 1) * TK, K, An + TM * TK, wave, lane);
+                stage_nt<BM, NW>(A, lda, m0, M, (kt + 1) * TK, K, An, wave, lane);
+            stage_nt<BN, NW>(B, ldb, n0, N, (kt + 1) * TK, K, An + BM * TK, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < TK / 32; ++ks) {
-            bf16x8 fw[4], fx[4];
+            bf16x8 fw[NJ], fx[MI];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fw[j] = frag_nt(Bs, wrow[j], ks * 4 + fg);
+            for (int j = 0; j < NJ; ++j) fw[j] = frag_nt(Bs, wrow[j], ks * 4 + fg);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fx[i] = frag_nt(As, wm * 64 + i * 16 + fr, ks * 4 + fg);
+            for (int i = 0; i < MI; ++i) fx[i] = frag_nt(As, wm * WTM + i * 16 + fr, ks * 4 + fg);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < NJ; ++j)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fx[i], acc[j][i], 0, 0, 0);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + fr;
-        const int n = n0 + wn * 64 + 16 * fg;
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + fr;
+        const int n = n0 + wn * WTN + 16 * fg;
         if (m < M && n < N) {
             float v[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[j][i][r];
             epi_row16<EPI, OutT>(epi, m, n, N, v);
@@ -281,42 +296,49 @@ __global__ __launch_bounds__(NT) void gemm_nt_fast_kernel(const bf16_t* __restri
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz_tn(int t) { return ((t & 3) | (((t >> 3) & 1) << 2)) << 1; }
 
-// stage one [64 t][128 cols] tile (256-B rows): wave w issues 4 loads, load i covers t = (4w+i)*4 .. +3
+// stage one [64 t][COLS] tile with NW waves: one load = 1 KiB = 512/COLS rows
+template <int COLS, int NW>
 __device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ g, long long ld, int t0, int T, int col0, int cols,
                                          bf16_t* lds, int wave, int lane) {
+    constexpr int CPR = COLS / 8;          // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;          // rows per load instruction
+    constexpr int PER = (64 / RPI) / NW;   // loads per wave
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int tblk = (wave * 4 + i) * 4;
-        const int t = tblk + (lane >> 4);
-        const int c = (lane & 15) ^ swz_tn(t);
+    for (int i = 0; i < PER; ++i) {
+        const int tblk = (wave * PER + i) * RPI;
+        const int t = tblk + lane / CPR;
+        const int c = (lane % CPR) ^ swz_tn(t);
         const int gt = t0 + t, gc = col0 + c * 8;
         const void* src = (gt < T && gc < cols) ? (const void*)(g + (long long)gt * ld + gc) : (const void*)g_zero16;
-        glds16(src, lds + tblk * 128);
+        glds16(src, lds + tblk * COLS);
     }
 }
 
+template <int COLS, int NW>
 __device__ __forceinline__ void stage_tn_patch(const bf16_t* __restrict__ img, const PatchGeom& pg, int t0, int col0,
                                                bf16_t* lds, int wave, int lane) {
+    constexpr int CPR = COLS / 8, RPI = 64 / CPR, PER = (64 / RPI) / NW;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int tblk = (wave * 4 + i) * 4;
-        const int t = tblk + (lane >> 4);
-        const int c = (lane & 15) ^ swz_tn(t);
+    for (int i = 0; i < PER; ++i) {
+        const int tblk = (wave * PER + i) * RPI;
+        const int t = tblk + lane / CPR;
+        const int c = (lane % CPR) ^ swz_tn(t);
         const int gt = t0 + t, gc = col0 + c * 8;
         const void* src = (gt < pg.tokens && gc < pg.elems) ? (const void*)(img + patch_addr(pg, gt, gc))
                                                             : (const void*)g_zero16;
-        glds16(src, lds + tblk * 128);
+        glds16(src, lds + tblk * COLS);
     }
 }
 
 // fragment for 16 consecutive columns col0..col0+15, k-step ks (32 t): element j of lane (fr,fg)
 // = tile[t = 32 ks + 8 fg + j][col0 + fr]
+template <int COLS>
 __device__ __forceinline__ bf16x8 frag_tn(const bf16_t* lds, int col0, int ks, int lane) {
     const int fg = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int col = col0 + 4 * p;              // 4 consecutive columns, 8 bytes
     const int t_lo = 32 * ks + 8 * fg + q, t_hi = t_lo + 4;
-    const int o_lo = t_lo * 128 + ((((col >> 3) ^ swz_tn(t_lo)) << 3) | (col & 7));
-    const int o_hi = t_hi * 128 + ((((col >> 3) ^ swz_tn(t_hi)) << 3) | (col & 7));
+    const int o_lo = t_lo * COLS + ((((col >> 3) ^ swz_tn(t_lo)) << 3) | (col & 7));
+    const int o_hi = t_hi * COLS + ((((col >> 3) ^ swz_tn(t_hi)) << 3) | (col & 7));
     typedef __attribute__((address_space(3))) s16x4* lp;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + o_lo));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(lds + o_hi));
@@ -329,73 +351,83 @@ __device__ __forceinline__ bf16x8 frag_tn(const bf16_t* lds, int col0, int ks, i
     return u.v;
 }
 
-template <bool PATCH>
-__global__ __launch_bounds__(NT) void gemm_tn_fast_kernel(const bf16_t* __restrict__ U, long long ldu,
-                                                          const bf16_t* __restrict__ V, long long ldv,
-                                                          float* __restrict__ C, long long ldc, long long slab_stride,
-                                                          int P, int Q, int T, int tiles_q, int kt_per_slab,
-                                                          PatchGeom pg) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * TK * 128];  // 64 KiB: U0 V0 U1 V1
-    const int tile = blockIdx.x;
-    const int p0 = (tile / tiles_q) * 128, q0 = (tile % tiles_q) * 128;
+// BP x BQ output tile, WP x WQ waves, each wave (BP/WP) x (BQ/WQ); dynamic LDS = two stages of
+// [64 t][BP + BQ] bf16
+template <bool PATCH, int BP, int BQ, int WP, int WQ>
+__global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t* __restrict__ U, long long ldu,
+                                                                    const bf16_t* __restrict__ V, long long ldv,
+                                                                    float* __restrict__ C, long long ldc,
+                                                                    long long slab_stride, int P, int Q, int T,
+                                                                    int tiles_q, int tiles_pq, int kt_per_slab,
+                                                                    PatchGeom pg) {
+    constexpr int NW = WP * WQ, WTP = BP / WP, WTQ = BQ / WQ, MI = WTP / 16, NJ = WTQ / 16;
+    constexpr int STAGE = TK * (BP + BQ);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    // 1-D grid of tiles x slabs, remapped so that each XCD (blocks b, b+8, ...) owns a contiguous run
+    // in which the tile index moves fastest: the blocks of one token slab run on one XCD at about
+    // the same time and share its L2 copy of the slab's U and V rows
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int slab = lin / tiles_pq, tile = lin - slab * tiles_pq;
+    const int p0 = (tile / tiles_q) * BP, q0 = (tile % tiles_q) * BQ;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wp = wave >> 1, wq = wave & 1;
+    const int wp = wave / WQ, wq = wave % WQ;
     const int fr = lane & 15, fg = lane >> 4;
     const int nk_all = (T + TK - 1) / TK;
-    const int kt_begin = blockIdx.z * kt_per_slab;
+    const int kt_begin = slab * kt_per_slab;
     const int kt_end = min(kt_begin + kt_per_slab, nk_all);
 
-    f32x4 acc[4][4];  // [j: q-tile][i: p-tile]
+    f32x4 acc[NJ][MI];  // [j: q-tile][i: p-tile]
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (kt_begin < kt_end) {
-        stage_tn(U, ldu, kt_begin * TK, T, p0, P, smem, wave, lane);
+        stage_tn<BP, NW>(U, ldu, kt_begin * TK, T, p0, P, smem, wave, lane);
         if (PATCH)
-            stage_tn_patch(V, pg, kt_begin * TK, q0, smem + TK * 128, wave, lane);
+            stage_tn_patch<BQ, NW>(V, pg, kt_begin * TK, q0, smem + TK * BP, wave, lane);
         else
-            stage_tn(V, ldv, kt_begin * TK, T, q0, Q, smem + TK * 128, wave, lane);
+            stage_tn<BQ, NW>(V, ldv, kt_begin * TK, T, q0, Q, smem + TK * BP, wave, lane);
     }
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const int b = (kt - kt_begin) & 1;
-        bf16_t* Us = smem + b * 2 * TK * 128;
-        bf16_t* Vs = Us + TK * 128;
+        bf16_t* Us = smem + b * STAGE;
+        bf16_t* Vs = Us + TK * BP;
         if (kt + 1 < kt_end) {
-            bf16_t* Un = smem + (b ^ 1) * 2 * TK * 128;
-            stage_tn(U, ldu, (kt + 1) * TK, T, p0, P, Un, wave, lane);
+            bf16_t* Un = smem + (b ^ 1) * STAGE;
+            stage_tn<BP, NW>(U, ldu, (kt + 1) * TK, T, p0, P, Un, wave, lane);
             if (PATCH)
-                stage_tn_patch(V, pg, (kt + 1) * TK, q0, Un + TK * 128, wave, lane);
+                stage_tn_patch<BQ, NW>(V, pg, (kt + 1) * TK, q0, Un + TK * BP, wave, lane);
             else
-                stage_tn(V, ldv, (kt + 1) * TK, T, q0, Q, Un + TK * 128, wave, lane);
+                stage_tn<BQ, NW>(V, ldv, (kt + 1) * TK, T, q0, Q, Un + TK * BP, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < TK / 32; ++ks) {
-            bf16x8 fv[4], fu[4];
+            bf16x8 fv[NJ], fu[MI];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fv[j] = frag_tn(Vs, wq * 64 + j * 16, ks, lane);
+            for (int j = 0; j < NJ; ++j) fv[j] = frag_tn<BQ>(Vs, wq * WTQ + j * 16, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fu[i] = frag_tn(Us, wp * 64 + i * 16, ks, lane);
+            for (int i = 0; i < MI; ++i) fu[i] = frag_tn<BP>(Us, wp * WTP + i * 16, ks, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < NJ; ++j)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[j], fu[i], acc[j][i], 0, 0, 0);
         }
         __syncthreads();
     }
-    // acc[j][i][r] = C[p = p0 + wp*64 + i*16 + fr][q = q0 + wq*64 + j*16 + 4*fg + r]
-    float* out = C + (long long)blockIdx.z * slab_stride;
+    // acc[j][i][r] = C[p = p0 + wp*WTP + i*16 + fr][q = q0 + wq*WTQ + j*16 + 4*fg + r]
+    float* out = C + (long long)slab * slab_stride;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = p0 + wp * 64 + i * 16 + fr;
+    for (int i = 0; i < MI; ++i) {
+        const int p = p0 + wp * WTP + i * 16 + fr;
         if (p >= P) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = q0 + wq * 64 + j * 16 + 4 * fg;
+        for (int j = 0; j < NJ; ++j) {
+            const int q = q0 + wq * WTQ + j * 16 + 4 * fg;
             if (q + 4 <= Q) {
                 *reinterpret_cast<f32x4*>(out + (long long)p * ldc + q) = acc[j][i];
             } else {
@@ -455,27 +487,69 @@ bool vitmi_gemm_nt_fast_ok(int M, int N, int K, const void* A, long long lda, co
     return true;
 }
 
+// Raise a kernel's dynamic-LDS limit once per device.
+static int ensure_lds_attr(const void* fn, size_t bytes, unsigned long long* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return vitmi_hip_fail(e, "hipGetDevice");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return VITMI_OK;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return vitmi_hip_fail(e, "hipFuncSetAttribute(LDS size)");
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+    return VITMI_OK;
+}
+
+template <int EPI, typename OutT, bool PATCH, int BM, int BN, int WM, int WN>
+static int launch_nt_cfg(int M, int N, int K, const bf16_t* a, long long lda, const bf16_t* b, long long ldb,
+                         const FastEpi& e, const PatchGeom& pg, hipStream_t s) {
+    static unsigned long long done = 0;
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * TK * sizeof(bf16_t);
+    auto fn = gemm_nt_fast_kernel<EPI, OutT, PATCH, BM, BN, WM, WN>;
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
+    if (rc != VITMI_OK) return rc;
+    const int tiles_m = ceil_div(M, BM), tiles_n = ceil_div(N, BN);
+    hipLaunchKernelGGL(fn, dim3(tiles_m * tiles_n), dim3(64 * WM * WN), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, pg);
+    VITMI_LAUNCH_CHECK("vitmi_gemm(nt fast)");
+    return VITMI_OK;
+}
+
+// tile configuration: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves, 4x2), 2 = 256x256 (8 waves, 2x4)
+static int g_nt_cfg_override = -1;
+extern "C" int vitmi_debug_set_nt_config(int cfg) {
+    g_nt_cfg_override = cfg;
+    return VITMI_OK;
+}
+
+static int pick_nt_cfg(int M, int N) {
+    if (g_nt_cfg_override >= 0) return g_nt_cfg_override;
+    // measured on the ViT-B/16 shapes: 256x256 tiles win (1.2-1.3x over 128x128) once they fill the
+    // 256 CUs at least once; 256x128 never wins
+    const long long tiles = (long long)ceil_div(M, 256) * ceil_div(N, 256);
+    return tiles >= 256 ? 2 : 0;
+}
+
+template <int EPI, typename OutT, bool PATCH>
+static int launch_nt_epi(int M, int N, int K, const bf16_t* a, long long lda, const bf16_t* b, long long ldb,
+                         const FastEpi& e, const PatchGeom& pg, hipStream_t s) {
+    switch (pick_nt_cfg(M, N)) {
+        case 2: return launch_nt_cfg<EPI, OutT, PATCH, 256, 256, 2, 4>(M, N, K, a, lda, b, ldb, e, pg, s);
+        case 1: return launch_nt_cfg<EPI, OutT, PATCH, 256, 128, 4, 2>(M, N, K, a, lda, b, ldb, e, pg, s);
+        default: return launch_nt_cfg<EPI, OutT, PATCH, 128, 128, 2, 2>(M, N, K, a, lda, b, ldb, e, pg, s);
+    }
+}
+
 template <bool PATCH>
 static int launch_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb,
                           const FastEpi& e, int c_dt, int epilogue, const PatchGeom& pg, hipStream_t s) {
-    const int tiles_m = ceil_div(M, TM), tiles_n = ceil_div(N, TN_);
-    dim3 grid(tiles_m * tiles_n), block(NT);
     const bf16_t* a = (const bf16_t*)A;
     const bf16_t* b = (const bf16_t*)B;
-    if (c_dt == VITMI_F32)
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_NONE, float, PATCH>), grid, block, 0, s, a, lda, b, ldb, e, M,
-                           N, K, tiles_n, pg);
-    else if (epilogue == VITMI_EPI_NONE)
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_NONE, bf16_t, PATCH>), grid, block, 0, s, a, lda, b, ldb, e,
-                           M, N, K, tiles_n, pg);
-    else if (epilogue == VITMI_EPI_GELU)
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_GELU, bf16_t, PATCH>), grid, block, 0, s, a, lda, b, ldb, e,
-                           M, N, K, tiles_n, pg);
-    else
-        hipLaunchKernelGGL((gemm_nt_fast_kernel<VITMI_EPI_DGELU, bf16_t, PATCH>), grid, block, 0, s, a, lda, b, ldb, e,
-                           M, N, K, tiles_n, pg);
-    VITMI_LAUNCH_CHECK("vitmi_gemm(nt fast)");
-    return VITMI_OK;
+    if (c_dt == VITMI_F32) return launch_nt_epi<VITMI_EPI_NONE, float, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+    if (epilogue == VITMI_EPI_NONE)
+        return launch_nt_epi<VITMI_EPI_NONE, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+    if (epilogue == VITMI_EPI_GELU)
+        return launch_nt_epi<VITMI_EPI_GELU, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+    return launch_nt_epi<VITMI_EPI_DGELU, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
 }
 
 int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
@@ -506,43 +580,70 @@ bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const voi
     return !(P % 8 || Q % 8 || ldu % 8 || ldv % 8 || ldc % 4 || !al16(U) || !al16(V) || !al16(C));
 }
 
+// tile configuration of the tn kernel: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves)
+static int g_tn_cfg_override = -1;
+extern "C" int vitmi_debug_set_tn_config(int cfg) {
+    g_tn_cfg_override = cfg;
+    return VITMI_OK;
+}
+static int pick_tn_cfg(int P, int Q) {
+    if (g_tn_cfg_override >= 0) return g_tn_cfg_override;
+    return (P >= 512 && Q >= 512) ? 1 : 0;
+}
+
 // number of t-slabs the tn kernel would use (the caller sizes the workspace from it)
 int vitmi_gemm_tn_slabs(int P, int Q, int T) {
-    const int tiles = ceil_div(P, 128) * ceil_div(Q, 128);
+    const int cfg = pick_tn_cfg(P, Q);
+    const int bt = cfg == 1 ? 256 : 128;
+    const int tiles = ceil_div(P, bt) * ceil_div(Q, bt);
     const int nk = ceil_div(T, TK);
-    int s = (512 + tiles - 1) / tiles;  // aim at ~2 resident blocks per CU on 256 CUs
+    const int target = cfg == 1 ? 256 : 512;  // resident blocks on 256 CUs
+    int s = (target + tiles - 1) / tiles;
     if (s > nk) s = nk;
     if (s > 32) s = 32;
     if (s < 1) s = 1;
     return s;
 }
 
-template <bool PATCH>
-static int launch_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
-                          long long ldc, float* slabs, const PatchGeom& pg, hipStream_t s) {
-    const int tiles_p = ceil_div(P, 128), tiles_q = ceil_div(Q, 128);
-    int ns = vitmi_gemm_tn_slabs(P, Q, T);
+template <bool PATCH, int BP, int BQ, int WP, int WQ>
+static int launch_tn_cfg(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
+                         long long ldc, float* slabs, int ns, const PatchGeom& pg, hipStream_t s) {
+    static unsigned long long done = 0;
+    constexpr size_t lds = 2 * (size_t)TK * (BP + BQ) * sizeof(bf16_t);
+    auto fn = gemm_tn_fast_kernel<PATCH, BP, BQ, WP, WQ>;
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
+    if (rc != VITMI_OK) return rc;
+    const int tiles_p = ceil_div(P, BP), tiles_q = ceil_div(Q, BQ);
     if (!slabs) ns = 1;
     const int nk = ceil_div(T, TK);
     const int per = ceil_div(nk, ns);
     ns = ceil_div(nk, per);
-    dim3 grid(tiles_p * tiles_q, 1, ns), block(NT);
+    dim3 grid(tiles_p * tiles_q * ns), block(64 * WP * WQ);
     if (ns == 1) {
-        hipLaunchKernelGGL(gemm_tn_fast_kernel<PATCH>, grid, block, 0, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
-                           C, ldc, 0ll, P, Q, T, tiles_q, per, pg);
+        hipLaunchKernelGGL(fn, grid, block, lds, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv, C, ldc, 0ll, P, Q, T,
+                           tiles_q, tiles_p * tiles_q, per, pg);
         VITMI_LAUNCH_CHECK("vitmi_gemm(tn fast)");
         return VITMI_OK;
     }
     // slabs are dense [ns][P][ldc] so that the reduce is a flat sum when C is dense
     const long long slab_stride = (long long)P * ldc;
-    hipLaunchKernelGGL(gemm_tn_fast_kernel<PATCH>, grid, block, 0, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
-                       slabs, ldc, slab_stride, P, Q, T, tiles_q, per, pg);
+    hipLaunchKernelGGL(fn, grid, block, lds, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv, slabs, ldc, slab_stride,
+                       P, Q, T, tiles_q, tiles_p * tiles_q, per, pg);
     VITMI_LAUNCH_CHECK("vitmi_gemm(tn fast)");
     const long long n4 = slab_stride / 4;
     int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, slab_stride, ns, C, n4);
     VITMI_LAUNCH_CHECK("vitmi_gemm(tn reduce)");
     return VITMI_OK;
+}
+
+template <bool PATCH>
+static int launch_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
+                          long long ldc, float* slabs, const PatchGeom& pg, hipStream_t s) {
+    const int ns = vitmi_gemm_tn_slabs(P, Q, T);
+    if (pick_tn_cfg(P, Q) == 1)
+        return launch_tn_cfg<PATCH, 256, 256, 2, 4>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s);
+    return launch_tn_cfg<PATCH, 128, 128, 2, 2>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s);
 }
 
 int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
