@@ -139,11 +139,14 @@ int vitmi_tokens_assemble_bwd(const void* dx, const long long* seq_ord, float* d
  * x rows are ldx apart (lets the head read x[:,0] in place); y is dense [rows,D]. */
 int vitmi_layernorm_fwd(const void* x, long long ldx, const float* gamma, const float* beta, void* y, float* mean,
                         float* rstd, int dt, long long rows, int D, float eps, void* stream);
-/* dx = LN'(dy) [+ dres]; dgamma/dbeta fp32 [D].  dres (dt, dense [rows,D]) may be NULL. */
+/* dx = LN'(dy) [+ dres]; dgamma/dbeta fp32 [D].  dres (dt, dense [rows,D]) may be NULL.
+ * dres_colsum (fp32 [D], may be NULL) receives the column sums of dres: dres is the gradient of the
+ * residual stream, whose column sum is the bias gradient of the projection that fed the residual,
+ * so that reduction rides on this kernel's pass over dres. */
 long long vitmi_layernorm_bwd_workspace_bytes(long long rows, int D);
 int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx, const float* gamma, const float* mean,
-                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta, void* workspace,
-                        int dt, long long rows, int D, void* stream);
+                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                        float* dres_colsum, void* workspace, int dt, long long rows, int D, void* stream);
 
 /* Multi-head self-attention core (mymodel/ViT.py:96-103): qkv is [B,N,3*H*DH] laid out as
  * the to_qkv output (q | k | v, each head-major), out is [B,N,H*DH] ('b h n d -> b n (h d)').

@@ -96,9 +96,13 @@ def test_layernorm(ops, dtype, rows, D):
     assert rel_err(y, yr) < TOL[dtype]
     assert rel_err(mean, xr.mean(-1)) < 1e-5 + (0 if dtype == torch.float32 else 1e-3)
     yr.backward(q(dy, dtype))
-    dx, dg, db = ops.layernorm_bwd(dy.to(DEV, dtype), xd, g.to(DEV), mean, rstd, dres=res.to(DEV, dtype))
+    dx, dg, db, rsum = ops.layernorm_bwd(dy.to(DEV, dtype), xd, g.to(DEV), mean, rstd, dres=res.to(DEV, dtype),
+                                         want_dres_colsum=True)
     assert rel_err(dx, xr.grad + q(res, dtype)) < TOL[dtype]
     assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    assert rel_err(rsum, q(res, dtype).double().sum(0)) < 1e-5       # fused bias-gradient reduction
+    dx2, _, _ = ops.layernorm_bwd(dy.to(DEV, dtype), xd, g.to(DEV), mean, rstd)
+    assert rel_err(dx2, xr.grad) < TOL[dtype]
 
 
 def test_layernorm_strided_rows(ops):

@@ -79,7 +79,7 @@ __device__ __forceinline__ void stage(const bf16_t* src, long long ld, int n, bf
 
 // ================================================================ forward (bf16)
 template <int DH, int NC>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, bf16_t* __restrict__ probs, int N,
                                                             int H, float scale) {
     using A = AttnDims<DH>;

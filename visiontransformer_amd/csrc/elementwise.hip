@@ -269,14 +269,14 @@ template <typename T, int V, int LN_MAX_ITERS>
 __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long long ldx,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const T* __restrict__ dres, T* __restrict__ dx,
-                                     float* __restrict__ partial, long long rows, int D) {
+                                     float* __restrict__ partial, long long rows, int D, int want_rsum) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    float dg[LN_MAX_ITERS][V], db[LN_MAX_ITERS][V], gm[LN_MAX_ITERS][V];
+    float dg[LN_MAX_ITERS][V], db[LN_MAX_ITERS][V], gm[LN_MAX_ITERS][V], dr[LN_MAX_ITERS][V];
 #pragma unroll
     for (int it = 0; it < LN_MAX_ITERS; ++it) {
         const int c = (it * 64 + lane) * V;
 #pragma unroll
-        for (int j = 0; j < V; ++j) dg[it][j] = db[it][j] = gm[it][j] = 0.f;
+        for (int j = 0; j < V; ++j) dg[it][j] = db[it][j] = gm[it][j] = dr[it][j] = 0.f;
         if (c < D) load_vec<float, V>(gamma + c, gm[it]);
     }
     for (long long row = (long long)blockIdx.x * nw + wave; row < rows; row += (long long)gridDim.x * nw) {
@@ -316,14 +316,17 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
                     float r[V];
                     load_vec<T, V>(dres + row * (long long)D + c, r);
 #pragma unroll
-                    for (int j = 0; j < V; ++j) o[j] += r[j];
+                    for (int j = 0; j < V; ++j) {
+                        o[j] += r[j];
+                        dr[it][j] += r[j];
+                    }
                 }
                 store_vec<T, V>(dxr + c, o);
             }
         }
     }
     // combine the block's waves through LDS, one iteration slice at a time
-    __shared__ float red[2][4][64 * V];
+    __shared__ float red[3][4][64 * V];
 #pragma unroll
     for (int it = 0; it < LN_MAX_ITERS; ++it) {
         if (it * 64 * V >= D) break;
@@ -332,6 +335,7 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
         for (int j = 0; j < V; ++j) {
             red[0][wave][lane * V + j] = dg[it][j];
             red[1][wave][lane * V + j] = db[it][j];
+            red[2][wave][lane * V + j] = dr[it][j];
         }
         __syncthreads();
         if (wave == 0) {
@@ -339,13 +343,15 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
             if (c < D) {
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    float a = 0.f, b = 0.f;
+                    float a = 0.f, b = 0.f, r = 0.f;
                     for (int w = 0; w < nw; ++w) {
                         a += red[0][w][lane * V + j];
                         b += red[1][w][lane * V + j];
+                        r += red[2][w][lane * V + j];
                     }
-                    partial[((long long)blockIdx.x * 2 + 0) * D + c + j] = a;
-                    partial[((long long)blockIdx.x * 2 + 1) * D + c + j] = b;
+                    partial[((long long)blockIdx.x * 3 + 0) * D + c + j] = a;
+                    partial[((long long)blockIdx.x * 3 + 1) * D + c + j] = b;
+                    if (want_rsum) partial[((long long)blockIdx.x * 3 + 2) * D + c + j] = r;
                 }
             }
         }
@@ -353,28 +359,33 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
 }
 
 __global__ void layernorm_bwd_final_kernel(const float* __restrict__ partial, int blocks, int D,
-                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                           float* __restrict__ rsum) {
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, r = 0.f;
     if (c < D)
         for (int k = grp; k < blocks; k += 4) {
-            a += partial[((long long)k * 2 + 0) * D + c];
-            b += partial[((long long)k * 2 + 1) * D + c];
+            a += partial[((long long)k * 3 + 0) * D + c];
+            b += partial[((long long)k * 3 + 1) * D + c];
+            if (rsum) r += partial[((long long)k * 3 + 2) * D + c];
         }
-    __shared__ float red[2][4][64];
+    __shared__ float red[3][4][64];
     red[0][grp][lane] = a;
     red[1][grp][lane] = b;
+    red[2][grp][lane] = r;
     __syncthreads();
     if (grp == 0 && c < D) {
         if (dgamma) dgamma[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
         if (dbeta) dbeta[c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+        if (rsum) rsum[c] = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
     }
 }
 
+// enough blocks for ~16 waves per CU on 256 CUs: the kernel streams 3-4 row-sized tensors
 inline int ln_bwd_blocks(long long rows) {
     long long b = (rows + 3) / 4;
-    if (b > 256) b = 256;
+    if (b > 1024) b = 1024;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -593,12 +604,14 @@ extern "C" int vitmi_layernorm_fwd(const void* x, long long ldx, const float* ga
 }
 
 extern "C" long long vitmi_layernorm_bwd_workspace_bytes(long long rows, int D) {
-    return (long long)ln_bwd_blocks(rows) * 2 * D * (long long)sizeof(float);
+    return (long long)ln_bwd_blocks(rows) * 3 * D * (long long)sizeof(float);
 }
 
 extern "C" int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx, const float* gamma, const float* mean,
                                    const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                   void* workspace, int dt, long long rows, int D, void* stream) {
+                                   float* dres_colsum, void* workspace, int dt, long long rows, int D,
+                                   void* stream) {
+    VITMI_CHECK_ARG(!dres_colsum || dres, "vitmi_layernorm_bwd: dres_colsum needs dres");
     VITMI_CHECK_ARG(dy && x && gamma && mean && rstd && dx && workspace, "vitmi_layernorm_bwd: null pointer");
     VITMI_CHECK_ARG(rows > 0 && D > 0 && ldx >= D, "vitmi_layernorm_bwd: bad shape");
     hipStream_t s = as_stream(stream);
@@ -620,7 +633,7 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx,
     dim3 grid(blocks), block(256);
 #define LN_BWD(T, V, I)                                                                                        \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, I>), grid, block, 0, s, (const T*)dy, (const T*)x, ldx, gamma, \
-                       mean, rstd, (const T*)dres, (T*)dx, partial, rows, D)
+                       mean, rstd, (const T*)dres, (T*)dx, partial, rows, D, dres_colsum ? 1 : 0)
 #define LN_BWD_I(T, V)                         \
     do {                                       \
         if (iters <= 1) LN_BWD(T, V, 1);       \
@@ -638,9 +651,9 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx,
 #undef LN_BWD_I
 #undef LN_BWD
     VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd");
-    if (dgamma || dbeta) {
+    if (dgamma || dbeta || dres_colsum) {
         hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, s, partial, blocks, D,
-                           dgamma, dbeta);
+                           dgamma, dbeta, dres_colsum);
         VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd(final)");
     }
     return VITMI_OK;

@@ -165,14 +165,18 @@ def layernorm_fwd(x2, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy2, x2, gamma, mean, rstd, dres=None, need_affine=True):
+def layernorm_bwd(dy2, x2, gamma, mean, rstd, dres=None, need_affine=True, want_dres_colsum=False):
+    """Returns (dx, dgamma, dbeta) and, with want_dres_colsum, the fp32 column sums of dres as a 4th value."""
     rows, D = x2.shape
     dx = torch.empty((rows, D), dtype=x2.dtype, device=x2.device)
     dg = torch.empty(D, dtype=torch.float32, device=x2.device) if need_affine else None
     db = torch.empty(D, dtype=torch.float32, device=x2.device) if need_affine else None
+    rs = torch.empty(D, dtype=torch.float32, device=x2.device) if want_dres_colsum else None
     ws = _ws(lib.vitmi_layernorm_bwd_workspace_bytes(rows, D), x2.device)
     check(lib.vitmi_layernorm_bwd(_p(dy2), _p(x2), x2.stride(0), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx),
-                                  _p(dg), _p(db), _p(ws), _dt(x2), rows, D, _stream()), "vitmi_layernorm_bwd")
+                                  _p(dg), _p(db), _p(rs), _p(ws), _dt(x2), rows, D, _stream()), "vitmi_layernorm_bwd")
+    if want_dres_colsum:
+        return dx, dg, db, rs
     return dx, dg, db
 
 
@@ -410,7 +414,8 @@ class AttnBlockFn(torch.autograd.Function):
         if w_out is not None:
             wo = compute_copy(w_out, cdt)
             dwo = linear_bwd_w(dy2, o2).to(w_out.dtype)
-            dbo = colsum(dy2).to(w_out.dtype) if has_bo else None
+            fuse_dbo = has_bo and has_ln and add_residual     # colsum(dy) rides on the LayerNorm backward
+            dbo = colsum(dy2).to(w_out.dtype) if (has_bo and not fuse_dbo) else None
             do = linear_bwd_x(dy2, wo, w_t=weight_t(w_out, cdt))
         else:
             do = dy2
@@ -421,7 +426,11 @@ class AttnBlockFn(torch.autograd.Function):
         dxn = linear_bwd_x(dqkv2, wq, w_t=weight_t(w_qkv, cdt))
         dg = db = None
         if has_ln:
-            dx, dg, db = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None)
+            if w_out is not None and fuse_dbo:
+                dx, dg, db, rs = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2, want_dres_colsum=True)
+                dbo = rs.to(w_out.dtype)
+            else:
+                dx, dg, db = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None)
             dg, db = dg.to(ln_dtype), db.to(ln_dtype)
         else:
             dx = add(dxn, dy2) if add_residual else dxn
@@ -463,14 +472,19 @@ class FFBlockFn(torch.autograd.Function):
         if xn is None:
             xn = x2
         dw2 = linear_bwd_w(dy2, h).to(w2.dtype)
-        db2 = colsum(dy2).to(w2.dtype)
+        fuse_db2 = has_ln and add_residual
+        db2 = None if fuse_db2 else colsum(dy2).to(w2.dtype)
         du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u, w_t=weight_t(w2, cdt))
         dw1 = linear_bwd_w(du, xn).to(w1.dtype)
         db1 = colsum(du).to(w1.dtype)
         dxn = linear_bwd_x(du, compute_copy(w1, cdt), w_t=weight_t(w1, cdt))
         dg = db = None
         if has_ln:
-            dx, dg, db = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None)
+            if fuse_db2:
+                dx, dg, db, rs = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2, want_dres_colsum=True)
+                db2 = rs.to(w2.dtype)
+            else:
+                dx, dg, db = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None)
             dg, db = dg.to(ln_dtype), db.to(ln_dtype)
         else:
             dx = add(dxn, dy2) if add_residual else dxn
