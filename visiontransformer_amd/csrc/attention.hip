@@ -17,6 +17,8 @@
 //                      (S^T, dP^T with the QUERY on the lane -> dS^T is the B operand).
 //             No atomics, no cross-wave reduction: results are bitwise reproducible.
 // fp32 kernels: one wave per query (or key) row, plain FMA; the parity path.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -37,10 +39,25 @@ __device__ __forceinline__ int perm_row(int c, int u, int i) { return 32 * c + 8
 template <int DH> struct AttnDims {
     static constexpr int KS = DH >= 32 ? DH / 32 : 1;   // 32-wide k-steps over the head dim
     static constexpr int DT = DH >= 16 ? DH / 16 : 1;   // 16-wide output tiles over the head dim
-    static constexpr int DHV = DH >= 16 ? DH : 16;      // rows of a transposed [d][seq] image
-    static constexpr int LDR = DH + 8;                  // row stride of a [seq][d] image (elements)
-    static constexpr int CPR = DH / 8;                  // 16-byte chunks per row
+    static constexpr int W = DH >= 16 ? DH : 16;        // row width of an LDS image (a dh=8 row is zero-padded)
+    static constexpr int CPR = W / 8;                   // 16-byte chunks per image row
 };
+
+// One LDS image per matrix, [seq][W] bf16 without padding, serves BOTH kinds of MFMA operand:
+//   row reads   (ds_read_b128: 8 consecutive head-dim elements of one sequence row) and
+//   transposed reads (ds_read_b64_tr_b16: 4 consecutive sequence rows of one head-dim column).
+// For 128-byte rows (dh = 64) chunk c of row r is stored at chunk c ^ swz(r) with
+// swz(r) = 2*bit1(r) | 4*bit3(r): the 16-lane groups of a row read (rows taken in the permuted
+// order of perm_row) and the 32-lane halves of a transposed read (rows 8g + q, g in {0,1}) then
+// touch every LDS bank exactly once.
+template <int DH>
+__device__ __forceinline__ int img_swz(int row) {
+    return AttnDims<DH>::W == 64 ? ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)) : 0;
+}
+template <int DH>
+__device__ __forceinline__ int img_off(int row, int chunk) {
+    return row * AttnDims<DH>::W + ((chunk ^ img_swz<DH>(row)) << 3);
+}
 
 // 16-byte fragment of row `row` of a [seq][DH] matrix in HBM (row stride ld), head-dim offset
 // ks*32 + 8*g; zero outside the matrix.
@@ -50,56 +67,71 @@ __device__ __forceinline__ bf16x8 global_frag(const bf16_t* base, long long ld, 
     if (row < nrows && d < DH) return *reinterpret_cast<const bf16x8*>(base + (long long)row * ld + d);
     return zero8();
 }
+// row read: elements [ks*32 + 8g, +8) of image row `row`
 template <int DH>
-__device__ __forceinline__ bf16x8 lds_row_frag(const bf16_t* img, int row, int ks, int g) {
+__device__ __forceinline__ bf16x8 row_frag(const bf16_t* img, int row, int ks, int g) {
     const int d = ks * 32 + g * 8;
-    if (d < DH) return *reinterpret_cast<const bf16x8*>(img + row * AttnDims<DH>::LDR + d);
+    if (d < DH) return *reinterpret_cast<const bf16x8*>(img + img_off<DH>(row, d >> 3));
     return zero8();
 }
+// transposed read: element j of lane (fr, fg) = image[seq0 + 8*fg + j][col0 + fr], j = 0..7
+template <int DH>
+__device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int seq0, int col0, int lane) {
+    const int fg = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int col = col0 + 4 * p;
+    const int r_lo = seq0 + 8 * fg + q, r_hi = r_lo + 4;
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(img + img_off<DH>(r_lo, col >> 3) + (col & 7)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(img + img_off<DH>(r_hi, col >> 3) + (col & 7)));
+    union {
+        s16x4 h[2];
+        bf16x8 v;
+    } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+}
 
-// stage rows [0,NP) of a [seq][DH] HBM matrix into a row image and/or a transposed image
-template <int DH, int NP, bool ROWS, bool TRANS>
-__device__ __forceinline__ void stage(const bf16_t* src, long long ld, int n, bf16_t* rows_img, bf16_t* trans_img) {
+// stage rows [0,NP) of a [seq][DH] HBM matrix (row stride ld) into an image; rows >= n and the
+// padding columns of a narrow head are zero
+template <int DH, int NP>
+__device__ __forceinline__ void stage_img(const bf16_t* src, long long ld, int n, bf16_t* img) {
     using A = AttnDims<DH>;
-    constexpr int LDT = NP + 8;
     for (int c = threadIdx.x; c < NP * A::CPR; c += blockDim.x) {
         const int r = c / A::CPR, kc = c % A::CPR;
         bf16x8 v = zero8();
-        if (r < n) v = *reinterpret_cast<const bf16x8*>(src + (long long)r * ld + kc * 8);
-        if (ROWS) *reinterpret_cast<bf16x8*>(rows_img + r * A::LDR + kc * 8) = v;
-        if (TRANS) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) trans_img[(kc * 8 + j) * LDT + r] = v[j];
-        }
-    }
-    if (TRANS && A::DHV > DH) {
-        for (int c = threadIdx.x; c < (A::DHV - DH) * LDT; c += blockDim.x) trans_img[DH * LDT + c] = (bf16_t)0.f;
+        if (r < n && kc * 8 < DH) v = *reinterpret_cast<const bf16x8*>(src + (long long)r * ld + kc * 8);
+        *reinterpret_cast<bf16x8*>(img + img_off<DH>(r, kc)) = v;
     }
 }
 
 // ================================================================ forward (bf16)
-template <int DH, int NC>
-__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// EXPORT is a template flag of the same kernel: the exported probabilities are the very bf16
+// values that feed P V.  Chunks of 32 keys that lie wholly beyond N are skipped, only the chunk
+// that straddles N pays for the key mask; exponentials are raw v_exp_f32.
+template <int DH, int NC, bool EXPORT>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, bf16_t* __restrict__ probs, int N,
                                                             int H, float scale) {
     using A = AttnDims<DH>;
-    constexpr int NP = NC * 32, LDT = NP + 8;
+    constexpr int NP = NC * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* VTs = Ks + NP * A::LDR;
+    bf16_t* Vs = Ks + NP * A::W;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
     const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
     const bf16_t* kb = qb + I;
     const bf16_t* vb = qb + 2 * I;
-    stage<DH, NP, true, false>(kb, ld, N, Ks, nullptr);
-    stage<DH, NP, false, true>(vb, ld, N, nullptr, VTs);
+    stage_img<DH, NP>(kb, ld, N, Ks);
+    stage_img<DH, NP>(vb, ld, N, Vs);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const float sl2 = scale * LOG2E;
+    const int nc_act = (N + 31) >> 5;                 // chunks that hold at least one real key
     for (int qt = wave; qt * 16 < N; qt += nwaves) {
         const int q = qt * 16 + fr;
         bf16x8 qf[A::KS];
@@ -107,68 +139,82 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(const bf16_t* __r
         for (int ks = 0; ks < A::KS; ++ks) qf[ks] = global_frag<DH>(qb, ld, q, N, ks, fg);
         // S^T tiles: s[c][u][r] = score(query q, key 32c + 8fg + 4u + r)
         f32x4 s[NC][2];
-#pragma unroll
-        for (int c = 0; c < NC; ++c)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                const int krow = perm_row(c, u, fr);
-#pragma unroll
-                for (int ks = 0; ks < A::KS; ++ks)
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(Ks, krow, ks, fg), qf[ks], acc, 0, 0, 0);
-                s[c][u] = acc;
-            }
         float mx = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+        for (int c = 0; c < NC; ++c) {
+            if (c < nc_act) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    const int krow = perm_row(c, u, fr);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = 32 * c + 8 * fg + 4 * u + r;
-                    if (key >= N) s[c][u][r] = -INFINITY;
-                    mx = fmaxf(mx, s[c][u][r]);
+                    for (int ks = 0; ks < A::KS; ++ks)
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(Ks, krow, ks, fg), qf[ks], acc, 0, 0,
+                                                                      0);
+                    s[c][u] = acc;
                 }
+                if (32 * c + 32 > N) {               // the one chunk that straddles N
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (32 * c + 8 * fg + 4 * u + r >= N) s[c][u][r] = -INFINITY;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    mx = fmaxf(fmaxf(mx, fmaxf(s[c][u][0], s[c][u][1])), fmaxf(s[c][u][2], s[c][u][3]));
+            }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mb = mx * sl2;
         float sum = 0.f;
 #pragma unroll
-        for (int c = 0; c < NC; ++c)
+        for (int c = 0; c < NC; ++c) {
+            if (c < nc_act) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f((s[c][u][r] - mx) * sl2);
-                    s[c][u][r] = p;
-                    sum += p;
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(fmaf(s[c][u][r], sl2, -mb));
+                        s[c][u][r] = p;
+                        sum += p;
+                    }
+            }
+        }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
-        const float inv = 1.f / sum;
-        if (fg == 0 && q < N) lse[((long long)b * H + h) * N + q] = mx * scale + logf(sum);
-        // O^T = V^T P^T, d-tile by d-tile
+        const float inv = __builtin_amdgcn_rcpf(sum);
+        if (fg == 0 && q < N) lse[((long long)b * H + h) * N + q] = mx * scale + __logf(sum);
+        // O^T = V^T P^T, d-tile by d-tile; V^T fragments come transposed out of the V row image
         f32x4 o[A::DT];
 #pragma unroll
         for (int dt = 0; dt < A::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            bf16x8 pf;
+            if (c < nc_act) {
+                bf16x8 pf;
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pf[4 * u + r] = (bf16_t)(s[c][u][r] * inv);
-            if (probs && q < N) {
-                bf16_t* prow = probs + (((long long)b * H + h) * N + q) * N;
+                    for (int r = 0; r < 4; ++r) pf[4 * u + r] = (bf16_t)(s[c][u][r] * inv);
+                if (EXPORT) {
+                    if (q < N) {
+                        bf16_t* prow = probs + (((long long)b * H + h) * N + q) * N + 32 * c + 8 * fg;
+                        if (32 * c + 32 <= N) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int key = 32 * c + 8 * fg + j;
-                    if (key < N) prow[key] = pf[j];
+                            for (int j = 0; j < 8; ++j) prow[j] = pf[j];
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (32 * c + 8 * fg + j < N) prow[j] = pf[j];
+                        }
+                    }
                 }
-            }
 #pragma unroll
-            for (int dt = 0; dt < A::DT; ++dt) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&VTs[(dt * 16 + fr) * LDT + 32 * c + 8 * fg]);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
+                for (int dt = 0; dt < A::DT; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Vs, 32 * c, dt * 16, lane), pf, o[dt],
+                                                                    0, 0, 0);
             }
         }
         if (q < N) {
@@ -195,13 +241,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
                                                                 const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     using A = AttnDims<DH>;
-    constexpr int NP = NC * 32, LDT = NP + 8;
+    constexpr int NP = NC * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* dOs = Qs + NP * A::LDR;
-    bf16_t* QTs = dOs + NP * A::LDR;
-    bf16_t* dOTs = QTs + A::DHV * LDT;
-    float* lse2 = reinterpret_cast<float*>(dOTs + A::DHV * LDT);
+    bf16_t* dOs = Qs + NP * A::W;
+    float* lse2 = reinterpret_cast<float*>(dOs + NP * A::W);
     float* delta = lse2 + NP;
 
     const int b = blockIdx.x / H, h = blockIdx.x % H;
@@ -212,8 +256,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
     const bf16_t* vb = qb + 2 * I;
     const bf16_t* ob = out + (long long)b * N * I + h * DH;
     const bf16_t* dob = dout + (long long)b * N * I + h * DH;
-    stage<DH, NP, true, true>(qb, ld, N, Qs, QTs);
-    stage<DH, NP, true, true>(dob, I, N, dOs, dOTs);
+    stage_img<DH, NP>(qb, ld, N, Qs);
+    stage_img<DH, NP>(dob, I, N, dOs);
     // lse (in log2 units) and delta = rowsum(dO * O) per query; padded queries get p = 0
     for (int q = threadIdx.x; q < NP; q += blockDim.x) {
         float l2 = 1e30f, dl = 0.f;
@@ -234,6 +278,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const float sl2 = scale * LOG2E;
+    const int nc_act = (N + 31) >> 5;
     for (int kt = wave; kt * 16 < N; kt += nwaves) {
         const int key = kt * 16 + fr;
         bf16x8 kf[A::KS], vf[A::KS];
@@ -246,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
 #pragma unroll
         for (int dt = 0; dt < A::DT; ++dt) dkt[dt] = dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int c = 0; c < NC; ++c) {
+        for (int c = 0; c < nc_act; ++c) {          // query chunks wholly beyond N contribute nothing
             bf16x8 pf, dsf;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -254,8 +299,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
                 f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < A::KS; ++ks) {
-                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(Qs, qrow, ks, fg), kf[ks], sa, 0, 0, 0);
-                    dpa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(dOs, qrow, ks, fg), vf[ks], dpa, 0, 0, 0);
+                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(Qs, qrow, ks, fg), kf[ks], sa, 0, 0, 0);
+                    dpa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(dOs, qrow, ks, fg), vf[ks], dpa, 0, 0, 0);
                 }
                 // this lane's rows are queries 32c + 8fg + 4u + r
                 const int q0 = 32 * c + 8 * fg + 4 * u;
@@ -263,17 +308,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
                 const f32x4 dl = *reinterpret_cast<const f32x4*>(&delta[q0]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = exp2f(sa[r] * sl2 - l2[r]);
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -l2[r]));
                     pf[4 * u + r] = (bf16_t)p;
                     dsf[4 * u + r] = (bf16_t)(p * (dpa[r] - dl[r]) * scale);
                 }
             }
 #pragma unroll
             for (int dt = 0; dt < A::DT; ++dt) {
-                const bf16x8 dof = *reinterpret_cast<const bf16x8*>(&dOTs[(dt * 16 + fr) * LDT + 32 * c + 8 * fg]);
-                const bf16x8 qtf = *reinterpret_cast<const bf16x8*>(&QTs[(dt * 16 + fr) * LDT + 32 * c + 8 * fg]);
-                dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dvt[dt], 0, 0, 0);
-                dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf, dkt[dt], 0, 0, 0);
+                dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(dOs, 32 * c, dt * 16, lane), pf, dvt[dt], 0,
+                                                                  0, 0);
+                dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Qs, 32 * c, dt * 16, lane), dsf, dkt[dt], 0,
+                                                                  0, 0);
             }
         }
         if (key < N) {
@@ -305,11 +350,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
                                                                const float* __restrict__ lse,
                                                                bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     using A = AttnDims<DH>;
-    constexpr int NP = NC * 32, LDT = NP + 8;
+    constexpr int NP = NC * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vs = Ks + NP * A::LDR;
-    bf16_t* KTs = Vs + NP * A::LDR;
+    bf16_t* Vs = Ks + NP * A::W;
 
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int I = H * DH;
@@ -319,13 +363,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
     const bf16_t* vb = qb + 2 * I;
     const bf16_t* ob = out + (long long)b * N * I + h * DH;
     const bf16_t* dob = dout + (long long)b * N * I + h * DH;
-    stage<DH, NP, true, true>(kb, ld, N, Ks, KTs);
-    stage<DH, NP, true, false>(vb, ld, N, Vs, nullptr);
+    stage_img<DH, NP>(kb, ld, N, Ks);
+    stage_img<DH, NP>(vb, ld, N, Vs);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const float sl2 = scale * LOG2E;
+    const int nc_act = (N + 31) >> 5;
     for (int qt = wave; qt * 16 < N; qt += nwaves) {
         const int q = qt * 16 + fr;
         bf16x8 qf[A::KS], dof[A::KS];
@@ -345,7 +390,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
 #pragma unroll
         for (int dt = 0; dt < A::DT; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int c = 0; c < NC; ++c) {
+        for (int c = 0; c < nc_act; ++c) {          // key chunks wholly beyond N contribute nothing
             bf16x8 dsf;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -353,22 +398,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __r
                 f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < A::KS; ++ks) {
-                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(Ks, krow, ks, fg), qf[ks], sa, 0, 0, 0);
-                    dpa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag<DH>(Vs, krow, ks, fg), dof[ks], dpa, 0, 0, 0);
+                    sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(Ks, krow, ks, fg), qf[ks], sa, 0, 0, 0);
+                    dpa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(Vs, krow, ks, fg), dof[ks], dpa, 0, 0, 0);
                 }
                 // this lane's rows are keys 32c + 8fg + 4u + r; padded keys contribute nothing
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = 32 * c + 8 * fg + 4 * u + r;
-                    const float p = key < N ? exp2f(sa[r] * sl2 - l2) : 0.f;
+                    float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -l2));
+                    if (32 * c + 32 > N && 32 * c + 8 * fg + 4 * u + r >= N) p = 0.f;   // straddling chunk only
                     dsf[4 * u + r] = (bf16_t)(p * (dpa[r] - dl) * scale);
                 }
             }
 #pragma unroll
-            for (int dt = 0; dt < A::DT; ++dt) {
-                const bf16x8 ktf = *reinterpret_cast<const bf16x8*>(&KTs[(dt * 16 + fr) * LDT + 32 * c + 8 * fg]);
-                dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dqt[dt], 0, 0, 0);
-            }
+            for (int dt = 0; dt < A::DT; ++dt)
+                dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Ks, 32 * c, dt * 16, lane), dsf, dqt[dt], 0,
+                                                                  0, 0);
         }
         if (q < N) {
             bf16_t* dq = dqkv + ((long long)b * N + q) * ld + h * DH;
@@ -575,15 +619,11 @@ inline int pick_nc(int N) {
 
 template <int DH, int NC>
 size_t dkv_smem() {
-    using A = AttnDims<DH>;
-    constexpr int NP = NC * 32, LDT = NP + 8;
-    return (size_t)(2 * NP * A::LDR + 2 * A::DHV * LDT) * sizeof(bf16_t) + 2 * NP * sizeof(float);
+    return (size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t) + 2 * NC * 32 * sizeof(float);
 }
 template <int DH, int NC>
 size_t dq_smem() {
-    using A = AttnDims<DH>;
-    constexpr int NP = NC * 32, LDT = NP + 8;
-    return (size_t)(2 * NP * A::LDR + A::DHV * LDT) * sizeof(bf16_t);
+    return (size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t);
 }
 
 // Raise a kernel's dynamic-LDS limit once per device (the attribute is per device; one process
@@ -602,22 +642,27 @@ inline int ensure_lds(const void* fn, size_t bytes, unsigned long long* done_mas
 
 template <int DH, int NC>
 size_t fwd_smem() {
-    using A = AttnDims<DH>;
-    constexpr int NP = NC * 32, LDT = NP + 8;
-    return (size_t)(NP * A::LDR + A::DHV * LDT) * sizeof(bf16_t);
+    return (size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t);
+}
+
+template <int DH, int NC, bool EXPORT>
+int launch_fwd_x(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
+    const float scale = 1.0f / sqrtf((float)DH);
+    static unsigned long long done = 0;
+    const size_t sm = fwd_smem<DH, NC>();
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH, NC, EXPORT>), sm, &done,
+                        "vitmi_attn_fwd: LDS attribute");
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC, EXPORT>), dim3(B * H), dim3(256), sm, s, (const bf16_t*)qkv,
+                       (bf16_t*)out, lse, (bf16_t*)probs, N, H, scale);
+    VITMI_LAUNCH_CHECK("vitmi_attn_fwd(bf16)");
+    return VITMI_OK;
 }
 
 template <int DH, int NC>
 int launch_fwd(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
-    const float scale = 1.0f / sqrtf((float)DH);
-    static unsigned long long done = 0;
-    const size_t sm = fwd_smem<DH, NC>();
-    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH, NC>), sm, &done, "vitmi_attn_fwd: LDS attribute");
-    if (rc != VITMI_OK) return rc;
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC>), dim3(B * H), dim3(256), sm, s, (const bf16_t*)qkv, (bf16_t*)out,
-                       lse, (bf16_t*)probs, N, H, scale);
-    VITMI_LAUNCH_CHECK("vitmi_attn_fwd(bf16)");
-    return VITMI_OK;
+    if (probs) return launch_fwd_x<DH, NC, true>(qkv, out, lse, probs, B, N, H, s);
+    return launch_fwd_x<DH, NC, false>(qkv, out, lse, probs, B, N, H, s);
 }
 
 template <int DH, int NC>
