@@ -24,6 +24,7 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr int ATTN_THREADS = 512;  // 8 waves per (image, head) workgroup
 
 __device__ __forceinline__ bf16x8 zero8() {
     bf16x8 z;
@@ -110,7 +111,7 @@ __device__ __forceinline__ void stage_img(const bf16_t* src, long long ld, int n
 // values that feed P V.  Chunks of 32 keys that lie wholly beyond N are skipped, only the chunk
 // that straddles N pays for the key mask; exponentials are raw v_exp_f32.
 template <int DH, int NC, bool EXPORT>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(ATTN_THREADS) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, bf16_t* __restrict__ probs, int N,
                                                             int H, float scale) {
     using A = AttnDims<DH>;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const bf16_t* __rest
 
 // ================================================================ backward dK, dV (bf16)
 template <int DH, int NC>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                 const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout,
                                                                 const float* __restrict__ lse,
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_kernel(const bf16_t* __
 
 // ================================================================ backward dQ (bf16)
 template <int DH, int NC>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ out,
                                                                const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse,
@@ -653,7 +654,7 @@ int launch_fwd_x(const void* qkv, void* out, float* lse, void* probs, int B, int
     int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH, NC, EXPORT>), sm, &done,
                         "vitmi_attn_fwd: LDS attribute");
     if (rc != VITMI_OK) return rc;
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC, EXPORT>), dim3(B * H), dim3(256), sm, s, (const bf16_t*)qkv,
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC, EXPORT>), dim3(B * H), dim3(ATTN_THREADS), sm, s, (const bf16_t*)qkv,
                        (bf16_t*)out, lse, (bf16_t*)probs, N, H, scale);
     VITMI_LAUNCH_CHECK("vitmi_attn_fwd(bf16)");
     return VITMI_OK;
@@ -675,10 +676,10 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     if (rc != VITMI_OK) return rc;
     rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_dq_bf16_kernel<DH, NC>), s2, &done2, "vitmi_attn_bwd: LDS attribute (dq)");
     if (rc != VITMI_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DH, NC>), dim3(B * H), dim3(256), s1, s, (const bf16_t*)qkv,
+    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DH, NC>), dim3(B * H), dim3(ATTN_THREADS), s1, s, (const bf16_t*)qkv,
                        (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
     VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dkv, bf16)");
-    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DH, NC>), dim3(B * H), dim3(256), s2, s, (const bf16_t*)qkv,
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DH, NC>), dim3(B * H), dim3(ATTN_THREADS), s2, s, (const bf16_t*)qkv,
                        (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
     VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dq, bf16)");
     return VITMI_OK;
