@@ -113,18 +113,30 @@ __global__ void colsum_partial_kernel(const T* __restrict__ x, long long rows, i
     }
 }
 
-// out[c] = sum_k partial[k][c], k ascending: 64 columns x 4 row-groups per block, the groups'
-// partial sums combined through LDS in a fixed order
-__global__ void colsum_final_kernel(const float* __restrict__ partial, int chunks, int cols, float* __restrict__ out) {
+// out[c] = sum_k partial[k][c] in a fixed order: 64 columns x 16 row groups per block, the groups'
+// partial sums combined through LDS
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ partial, int chunks, int cols,
+                                                            float* __restrict__ out) {
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < cols)
-        for (int k = grp; k < chunks; k += 4) s += partial[(long long)k * cols + c];
-    __shared__ float red[4][64];
-    red[grp][lane] = s;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < cols) {
+        int k = grp;
+        for (; k + 16 < chunks; k += 32) {
+            s0 += partial[(long long)k * cols + c];
+            s1 += partial[(long long)(k + 16) * cols + c];
+        }
+        for (; k < chunks; k += 16) s0 += partial[(long long)k * cols + c];
+    }
+    __shared__ float red[16][64];
+    red[grp][lane] = s0 + s1;
     __syncthreads();
-    if (grp == 0 && c < cols) out[c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (grp == 0 && c < cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g][lane];
+        out[c] = s;
+    }
 }
 
 inline int colsum_chunks(long long rows) {
@@ -150,7 +162,7 @@ int launch_colsum(const void* x, long long rows, int cols, long long ld, float* 
                            rows_per_chunk);
     }
     VITMI_LAUNCH_CHECK("vitmi_colsum(partial)");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, s, partial, chunks, cols, out);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 64)), dim3(1024), 0, s, partial, chunks, cols, out);
     VITMI_LAUNCH_CHECK("vitmi_colsum(final)");
     return VITMI_OK;
 }
@@ -358,27 +370,39 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
     }
 }
 
-__global__ void layernorm_bwd_final_kernel(const float* __restrict__ partial, int blocks, int D,
-                                           float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                           float* __restrict__ rsum) {
+// out[q][c] = sum_k partial[k][q][c] in a fixed order.  Block (column strip, quantity q): 16 row
+// groups x 64 columns, each group keeps four independent running sums so that the loads of a
+// thread overlap instead of forming one dependent chain.
+__global__ __launch_bounds__(1024) void layernorm_bwd_final_kernel(const float* __restrict__ partial, int blocks,
+                                                                   int D, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta,
+                                                                   float* __restrict__ rsum) {
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float a = 0.f, b = 0.f, r = 0.f;
-    if (c < D)
-        for (int k = grp; k < blocks; k += 4) {
-            a += partial[((long long)k * 3 + 0) * D + c];
-            b += partial[((long long)k * 3 + 1) * D + c];
-            if (rsum) r += partial[((long long)k * 3 + 2) * D + c];
+    const int q = blockIdx.y;
+    float* out = q == 0 ? dgamma : (q == 1 ? dbeta : rsum);
+    if (!out) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < D) {
+        const float* p = partial + (long long)q * D + c;
+        const long long st = 3ll * D;
+        int k = grp;
+        for (; k + 48 < blocks; k += 64) {
+            a0 += p[(long long)k * st];
+            a1 += p[(long long)(k + 16) * st];
+            a2 += p[(long long)(k + 32) * st];
+            a3 += p[(long long)(k + 48) * st];
         }
-    __shared__ float red[3][4][64];
-    red[0][grp][lane] = a;
-    red[1][grp][lane] = b;
-    red[2][grp][lane] = r;
+        for (; k < blocks; k += 16) a0 += p[(long long)k * st];
+    }
+    __shared__ float red[16][64];
+    red[grp][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (grp == 0 && c < D) {
-        if (dgamma) dgamma[c] = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-        if (dbeta) dbeta[c] = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-        if (rsum) rsum[c] = red[2][0][lane] + red[2][1][lane] + red[2][2][lane] + red[2][3][lane];
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g][lane];
+        out[c] = s;
     }
 }
 
@@ -652,7 +676,7 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx,
 #undef LN_BWD
     VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd");
     if (dgamma || dbeta || dres_colsum) {
-        hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(ceil_div(D, 64)), dim3(256), 0, s, partial, blocks, D,
+        hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(ceil_div(D, 64), 3), dim3(1024), 0, s, partial, blocks, D,
                            dgamma, dbeta, dres_colsum);
         VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd(final)");
     }
