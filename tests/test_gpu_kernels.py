@@ -252,8 +252,10 @@ def test_cast_add_meanpool(ops):
 
 
 # ------------------------------------------------------------------------------------------ aligned fast paths
+# the last three have >= 256 output tiles and K % 64 == 0: the persistent phased kernel (ragged M and N
+# edges, one / two / three K-tiles, blocks that walk more than one tile)
 @pytest.mark.parametrize("M,N,K", [(394, 768, 768), (1000, 2304, 768), (520, 768, 3072), (129, 136, 72), (5, 8, 8),
-                                   (256, 256, 4096)])
+                                   (256, 256, 4096), (16500, 1032, 192), (20000, 1024, 64), (20000, 1024, 128)])
 def test_fast_nt_gemm_all_epilogues(ops, M, N, K):
     dtype = torch.bfloat16
     x, w, b, r = rnd(M, K, seed=21), rnd(N, K, seed=22, scale=K ** -0.5), rnd(N, seed=23), rnd(M, N, seed=24)
@@ -279,8 +281,9 @@ def test_fast_nt_gemm_all_epilogues(ops, M, N, K):
     assert rel_err(du, a.grad) < 1e-2
 
 
+# T % 64 == 0 with P, Q >= 512 takes the phased kernel (ragged P and Q edges, one and two token tiles)
 @pytest.mark.parametrize("T,P,Q", [(6304, 768, 768), (1576, 2304, 768), (12608, 768, 3072), (197, 96, 192), (64, 8, 8),
-                                   (1000, 136, 520)])
+                                   (1000, 136, 520), (640, 520, 1032), (64, 768, 768), (128, 512, 520)])
 def test_fast_weight_gradient_gemm(ops, T, P, Q):
     dtype = torch.bfloat16
     dy, x = rnd(T, P, seed=31), rnd(T, Q, seed=32)

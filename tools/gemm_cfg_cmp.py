@@ -40,5 +40,9 @@ for N, K in [(2304, 768), (768, 768), (3072, 768), (768, 3072), (768, 2304)]:
         err = ((y[:4096].float() - ref).abs().max() / ref.abs().max()).item()
         tail = (y[-300:].float() - x[-300:].float() @ w.float().t()).abs().max().item()
         ms = timeit(lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16))
-        print(f"nt {T}x{N}x{K} cfg {cfg}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF  rel err {err:.2e} tail {tail:.2e}", flush=True)
+        ms_al = timeit(lambda: ops.gemm_raw(BF16, T, N, K, x, 0, 1, w, 0, 1, y, N, BF16))
+        xz, wz = torch.zeros_like(x), torch.zeros_like(w)
+        ms_z = timeit(lambda: ops.gemm_raw(BF16, T, N, K, xz, K, 1, wz, K, 1, y, N, BF16))
+        print(f"nt {T}x{N}x{K} cfg {cfg}: {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF  rel err {err:.2e} tail {tail:.2e}"
+              f" | aliased rows {fl / ms_al / 1e9:7.1f} TF | zero operands {fl / ms_z / 1e9:7.1f} TF", flush=True)
 lib.vitmi_debug_set_nt_config(-1)

@@ -18,6 +18,8 @@
 //
 // Out-of-range rows/chunks are fetched from a 16-byte zero word instead of being clamped, so
 // ragged M, N, K contribute exact zeros.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -102,22 +104,24 @@ struct FastEpi {
     long long group_stride;
 };
 
-template <int EPI, typename OutT>
+// v[t] belongs to row m, column n + (t & 7) + (t >> 3) * H2: two runs of 8 consecutive columns, H2
+// apart (H2 = 8: one run of 16)
+template <int EPI, typename OutT, int H2 = 8>
 __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N, float (&v)[16]) {
-    // v[t] belongs to column n + t of row m
-    const bool full = (n + 16 <= N);
+    const bool full = (n + H2 + 8 <= N);
+    auto col = [&](int t) { return n + (t & 7) + (t >> 3) * H2; };
     if (e.bias) {
         if (full) {
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + n + 4 * t4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(e.bias + col(4 * t4));
 #pragma unroll
                 for (int t = 0; t < 4; ++t) v[4 * t4 + t] += b[t];
             }
         } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t)
-                if (n + t < N) v[t] += e.bias[n + t];
+                if (col(t) < N) v[t] += e.bias[col(t)];
         }
     }
     if (EPI == VITMI_EPI_GELU) {
@@ -131,11 +135,11 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
                     p1[t] = (bf16_t)v[8 + t];
                 }
                 *reinterpret_cast<bf16x8*>(a) = p0;
-                *reinterpret_cast<bf16x8*>(a + 8) = p1;
+                *reinterpret_cast<bf16x8*>(a + H2) = p1;
             } else {
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
-                    if (n + t < N) a[t] = (bf16_t)v[t];
+                    if (col(t) < N) a[col(t) - n] = (bf16_t)v[t];
             }
         }
 #pragma unroll
@@ -144,7 +148,7 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
         const bf16_t* a = e.aux + (long long)m * e.ldaux + n;
         if (full) {
             const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a);
-            const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a + 8);
+            const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a + H2);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 v[t] *= gelu_grad_fast((float)p0[t]);
@@ -153,14 +157,14 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
         } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t)
-                if (n + t < N) v[t] *= gelu_grad_fast((float)a[t]);
+                if (col(t) < N) v[t] *= gelu_grad_fast((float)a[col(t) - n]);
         }
     }
     if (e.res) {
         const bf16_t* r = e.res + (long long)m * e.ldr + n;
         if (full) {
             const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(r);
-            const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(r + 8);
+            const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(r + H2);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 v[t] += (float)p0[t];
@@ -169,7 +173,7 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
         } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t)
-                if (n + t < N) v[t] += (float)r[t];
+                if (col(t) < N) v[t] += (float)r[col(t) - n];
         }
     }
     OutT* c = reinterpret_cast<OutT*>(e.C) + (long long)m * e.ldc + n;
@@ -187,17 +191,17 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
                 p1[t] = (bf16_t)v[8 + t];
             }
             *reinterpret_cast<bf16x8*>(c) = p0;
-            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(c) + 8) = p1;
+            *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(c) + H2) = p1;
         } else {
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4)
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(c) + 4 * t4) =
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(c) + (col(4 * t4) - n)) =
                     f32x4{v[4 * t4], v[4 * t4 + 1], v[4 * t4 + 2], v[4 * t4 + 3]};
         }
     } else {
 #pragma unroll
         for (int t = 0; t < 16; ++t)
-            if (n + t < N) c[t] = from_f32<OutT>(v[t]);
+            if (col(t) < N) c[col(t) - n] = from_f32<OutT>(v[t]);
     }
 }
 
@@ -289,6 +293,217 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(const bf16_t
             epi_row16<EPI, OutT>(epi, m, n, N, v);
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// nt kernel, phased variant for large problems with K % 64 == 0.  256x256 block tile, 8 waves as
+// 2 (m) x 4 (n), 64-deep K-tiles double-buffered in LDS.  A K-tile is four phases of 16 MFMAs (one
+// quadrant of the wave's 128x64 sub-tile each); a phase is
+//     [fragment reads + one 16-KiB region of direct-to-LDS loads] barrier [16 MFMAs] barrier
+// and the two wave groups (m halves; one wave of each per SIMD) run one barrier apart, so one
+// group's MFMAs execute beside the other group's LDS/VMEM work.
+//
+// A K-tile buffer is four regions of 128 rows x 64 k, cut by WHEN a row is read, not by where it
+// sits in the matrix:  RA0 = the m rows of quadrants 0/1 of both groups, RB0 = the n rows of the
+// two n-tiles used in phases 0 and 3 (the first 32 of each wave's 64 columns), RB1 = those of
+// phases 1 and 2, RA1 = the m rows of phases
+// 2/3.  Regions are streamed in that order, phase q issues region q+6 of the stream, and a
+// counted s_waitcnt vmcnt(8) leaves four regions (64 KiB per CU) in flight across the barriers.
+//   RAW: the wait that retires a region precedes the first barrier of the phase BEFORE its first
+//        read, so both groups have passed a barrier after every wave's wait.
+//   WAR: a region is refilled at least two phases after the phase that last read it.
+// ------------------------------------------------------------------------------------------------
+constexpr int RG = 128 * TK;  // elements per region
+
+__device__ __forceinline__ void wait_vm_regions(int pend) {  // 2 loads per wave per region
+    if (pend >= 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (pend == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (pend == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (pend == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __restrict__ A, long long lda,
+                                                             const bf16_t* __restrict__ B, long long ldb,
+                                                             FastEpi epi, int M, int N, int K, int tiles_n,
+                                                             int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nreg = 4 * (K / TK);  // regions in the stream
+    // persistent: the grid is one block per CU (a multiple of 8, so a block keeps its XCD); output
+    // stores of a tile drain while the next tile's loads and MFMAs run
+    for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    const int tile = xcd_remap(vb, ntiles);
+    const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+
+    // A region is 16 loads of 8 rows; wave w issues loads 2w and 2w+1 of every region.  src[s][i]:
+    // per-lane source of load i of the next region of kind s (0 RA0, 1 RB0, 2 RB1, 3 RA1); rows
+    // past the edge read the zero word and do not advance.
+    const char* src[4][2];
+    int inc[4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rho = (wave * 2 + i) * 8 + (lane >> 3);  // row inside the region
+        const int c = (lane & 7) ^ swz_nt(rho);
+        const int ra = (rho >> 6) * 128 + (rho & 63);           // RA0 row; RA1 = + 64
+        const int rb = (rho >> 5) * 64 + (rho & 31);            // RB0 row; RB1 = + 32
+        const int rows[4] = {ra, rb, rb + 32, ra + 64};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const bool isA = (s4 == 0 || s4 == 3);
+            const int g = (isA ? m0 : n0) + rows[s4];
+            const bool ok = g < (isA ? M : N);
+            const bf16_t* base = isA ? A + (long long)g * lda : B + (long long)g * ldb;
+            src[s4][i] = ok ? (const char*)(base + c * 8) : (const char*)g_zero16;
+            inc[s4][i] = ok ? TK * 2 : 0;
+        }
+    }
+    // issue region h of the stream (kind h & 3 of K-tile h >> 2); regions go out strictly in order
+    auto stage = [&](int h, auto kind) {
+        constexpr int S = decltype(kind)::value;
+        bf16_t* dst = smem + ((h >> 2) & 1) * 4 * RG + S * RG + wave * 2 * 8 * TK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            glds16(src[S][i], dst + i * 8 * TK);
+            src[S][i] += inc[S][i];
+        }
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+
+    // fragment rows inside their regions
+    int rowX[4], rowW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowX[i] = wr * 64 + i * 16 + fr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) rowW[j] = wc * 32 + 8 * (fr >> 2) + 4 * j + (fr & 3);
+    auto frag = [&](const bf16_t* region, int row, int ks) {
+        return *reinterpret_cast<const bf16x8*>(region + row * TK + (((ks * 4 + fg) ^ swz_nt(row)) << 3));
+    };
+
+    f32x4 acc[4][8];  // [j: n-tile][i: m-tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: regions 0..5, regions 0 and 1 landed
+    stage(0, K0{});
+    stage(1, K1{});
+    stage(2, K2{});
+    stage(3, K3{});
+    if (nreg > 4) {
+        stage(4, K0{});
+        stage(5, K1{});
+    }
+    wait_vm_regions(min(nreg, 6) - 2);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // second group runs one barrier behind
+
+    bf16x8 fx[4][2], fw0[2][2], fw1[2][2];
+    for (int q = 0; q < nreg; q += 4) {
+        const bf16_t* buf = smem + ((q >> 2) & 1) * 4 * RG;
+        // ---- phase 0: quadrant (m 0-3, n 0-1)
+        if (q + 6 < nreg) stage(q + 6, K2{});
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fw0[j][ks] = frag(buf + RG, rowW[j], ks);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fx[i][ks] = frag(buf, rowX[i], ks);
+        wait_vm_regions(min(nreg, q + 7) - (q + 3));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[j][ks], fx[i][ks], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 1: quadrant (m 0-3, n 2-3)
+        if (q + 7 < nreg) stage(q + 7, K3{});
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fw1[j][ks] = frag(buf + 2 * RG, rowW[j], ks);
+        wait_vm_regions(min(nreg, q + 8) - (q + 4));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[2 + j][i] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[j][ks], fx[i][ks], acc[2 + j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: quadrant (m 4-7, n 2-3)
+        if (q + 8 < nreg) stage(q + 8, K0{});
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fx[i][ks] = frag(buf + 3 * RG, rowX[i], ks);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[2 + j][4 + i] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[j][ks], fx[i][ks], acc[2 + j][4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: quadrant (m 4-7, n 0-1); nothing to read
+        if (q + 9 < nreg) stage(q + 9, K1{});
+        wait_vm_regions(min(nreg, q + 10) - (q + 6));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j][4 + i] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw0[j][ks], fx[i][ks], acc[j][4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // matches the second group's extra barrier
+
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + fr;
+        const int n = n0 + wc * 64 + 8 * fg;
+        if (m < M && n < N) {
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[j][i][r];
+            epi_row16<EPI, OutT, 32>(epi, m, n, N, v);
+        }
+    }
+    }  // tile loop
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -439,6 +654,220 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// tn kernel, phased variant (T % 64 == 0): the schedule of gemm_nt_phased_kernel (four phases of 16
+// MFMAs per 64-deep token tile, two wave groups one barrier apart, regions streamed six ahead
+// with a counted vmcnt) on [64 t][128 cols] regions read through ds_read_b64_tr_b16:
+//   RU0 = p columns of the first 64 of each group's 128, RV0 = first 32 of each wave's 64 q
+//   columns, RV1 = the other 32, RU1 = the other 64 p columns.
+// The transposed reads are issued from inline assembly: hipcc puts s_waitcnt vmcnt(0) in front of
+// the ds_read_tr builtin whenever a direct-to-LDS load is outstanding, which would serialise every
+// token tile behind its own loads.  Their results are therefore covered by the explicit
+// lgkmcnt(0) that follows each phase's first barrier.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x2 tr_read(unsigned lds_addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr) : "memory");
+    return r;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_phased_kernel(const bf16_t* __restrict__ U, long long ldu,
+                                                             const bf16_t* __restrict__ V, long long ldv,
+                                                             float* __restrict__ C, long long ldc,
+                                                             long long slab_stride, int P, int Q, int tiles_q,
+                                                             int tiles_pq, int kt_per_slab, int nk_all) {
+    constexpr int RGT = TK * 128;  // elements per region: 64 t x 128 columns
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    typedef __attribute__((address_space(3))) unsigned char* lds_u8p;
+    const unsigned lds_base = (unsigned)(size_t)(lds_u8p)smem_raw;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int slab = lin / tiles_pq, tile = lin - slab * tiles_pq;
+    const int p0 = (tile / tiles_q) * 256, q0 = (tile % tiles_q) * 256;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int kt_begin = slab * kt_per_slab;
+    const int kt_end = min(kt_begin + kt_per_slab, nk_all);
+    const int nreg = 4 * max(kt_end - kt_begin, 0);
+
+    // a region is 16 loads of 4 token rows; wave w issues loads 2w and 2w+1 of every region
+    const char* src[4][2];
+    long long inc[4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int tl = (wave * 2 + i) * 4 + (lane >> 4);  // token row inside the tile
+        const int lc = ((lane & 15) ^ swz_tn(tl)) * 8;    // first of 8 logical columns
+        const int cu = (lc >> 6) * 128 + (lc & 63);       // RU0 column; RU1 = + 64
+        const int cv = (lc >> 5) * 64 + (lc & 31);        // RV0 column; RV1 = + 32
+        const int cols[4] = {cu, cv, cv + 32, cu + 64};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const bool isU = (s4 == 0 || s4 == 3);
+            const int g = (isU ? p0 : q0) + cols[s4];
+            const bool ok = g < (isU ? P : Q);
+            const long long ld = isU ? ldu : ldv;
+            const bf16_t* base = (isU ? U : V) + ((long long)kt_begin * TK + tl) * ld + g;
+            src[s4][i] = ok ? (const char*)base : (const char*)g_zero16;
+            inc[s4][i] = ok ? ld * TK * 2 : 0;
+        }
+    }
+    auto stage = [&](int h, auto kind) {
+        constexpr int S = decltype(kind)::value;
+        bf16_t* dst = smem + ((h >> 2) & 1) * 4 * RGT + S * RGT + wave * 2 * 4 * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            glds16(src[S][i], dst + i * 4 * 128);
+            src[S][i] += inc[S][i];
+        }
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+
+    // fragment of 16 consecutive region columns col0.., k-step ks: element j of lane (fr, fg) =
+    // region[t = 32 ks + 8 fg + j][col0 + fr]; byte offsets of its two transposed reads
+    const int tq = (lane >> 2) & 3, tp = lane & 3;
+    auto frag_off = [&](int col0, int ks, int half) {
+        const int col = col0 + 4 * tp;
+        const int t = 32 * ks + 8 * fg + tq + 4 * half;
+        return 2 * (t * 128 + ((((col >> 3) ^ swz_tn(t)) << 3) | (col & 7)));
+    };
+    auto frag = [&](unsigned region_addr, int col0, int ks) {
+        union {
+            u32x2 h[2];
+            bf16x8 v;
+        } u;
+        u.h[0] = tr_read(region_addr + frag_off(col0, ks, 0));
+        u.h[1] = tr_read(region_addr + frag_off(col0, ks, 1));
+        return u.v;
+    };
+
+    f32x4 acc[4][8];  // [j: q-tile][i: p-tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nreg > 0) {
+        stage(0, K0{});
+        stage(1, K1{});
+        stage(2, K2{});
+        stage(3, K3{});
+        if (nreg > 4) {
+            stage(4, K0{});
+            stage(5, K1{});
+        }
+    }
+    wait_vm_regions(min(nreg, 6) - 2);
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    bf16x8 fu[4][2], fv0[2][2], fv1[2][2];
+    for (int q = 0; q < nreg; q += 4) {
+        const unsigned buf = lds_base + ((q >> 2) & 1) * 4 * RGT * 2;
+        // ---- phase 0: quadrant (p 0-3, q 0-1)
+        if (q + 6 < nreg) stage(q + 6, K2{});
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fv0[j][ks] = frag(buf + RGT * 2, wc * 32 + j * 16, ks);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fu[i][ks] = frag(buf, wr * 64 + i * 16, ks);
+        wait_vm_regions(min(nreg, q + 7) - (q + 3));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[j][ks], fu[i][ks], acc[j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 1: quadrant (p 0-3, q 2-3)
+        if (q + 7 < nreg) stage(q + 7, K3{});
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fv1[j][ks] = frag(buf + 2 * RGT * 2, wc * 32 + j * 16, ks);
+        wait_vm_regions(min(nreg, q + 8) - (q + 4));
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[2 + j][i] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[j][ks], fu[i][ks], acc[2 + j][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2: quadrant (p 4-7, q 2-3)
+        if (q + 8 < nreg) stage(q + 8, K0{});
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fu[i][ks] = frag(buf + 3 * RGT * 2, wr * 64 + i * 16, ks);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[2 + j][4 + i] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv1[j][ks], fu[i][ks], acc[2 + j][4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3: quadrant (p 4-7, q 0-1); nothing to read
+        if (q + 9 < nreg) stage(q + 9, K1{});
+        wait_vm_regions(min(nreg, q + 10) - (q + 6));
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[j][4 + i] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv0[j][ks], fu[i][ks], acc[j][4 + i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    // acc[j][i][r] = C[p = p0 + wr*128 + i*16 + fr][q = q0 + wc*64 + j*16 + 4*fg + r]
+    float* out = C + (long long)slab * slab_stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int pp = p0 + wr * 128 + i * 16 + fr;
+        if (pp >= P) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int qq = q0 + wc * 64 + j * 16 + 4 * fg;
+            if (qq + 4 <= Q) {
+                *reinterpret_cast<f32x4*>(out + (long long)pp * ldc + qq) = acc[j][i];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (qq + r < Q) out[(long long)pp * ldc + qq + r] = acc[j][i][r];
+            }
+        }
+    }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int nslabs,
                                    float* __restrict__ out, long long n4) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -514,7 +943,40 @@ static int launch_nt_cfg(int M, int N, int K, const bf16_t* a, long long lda, co
     return VITMI_OK;
 }
 
-// tile configuration: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves, 4x2), 2 = 256x256 (8 waves, 2x4)
+// persistent blocks of the phased nt kernel: one per CU, rounded down to a multiple of 8 so that a
+// block's tiles stay on its XCD
+static int phased_grid_blocks() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cached[dev & 63];
+    if (c == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+        c = cus & ~7;
+    }
+    return c;
+}
+
+template <int EPI, typename OutT>
+static int launch_nt_phased(int M, int N, int K, const bf16_t* a, long long lda, const bf16_t* b, long long ldb,
+                            const FastEpi& e, hipStream_t s) {
+    static unsigned long long done = 0;
+    constexpr size_t lds = 2 * 4 * (size_t)RG * sizeof(bf16_t);
+    auto fn = gemm_nt_phased_kernel<EPI, OutT>;
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
+    if (rc != VITMI_OK) return rc;
+    const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 256);
+    const int ntiles = tiles_m * tiles_n;
+    int grid = ntiles;
+    if (grid > phased_grid_blocks()) grid = phased_grid_blocks();
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles);
+    VITMI_LAUNCH_CHECK("vitmi_gemm(nt phased)");
+    return VITMI_OK;
+}
+
+// tile configuration: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves, 4x2), 2 = 256x256 (8 waves, 2x4),
+// 3 = 256x256 phased (K % 64 == 0, not for the patch operand)
 static int g_nt_cfg_override = -1;
 extern "C" int vitmi_debug_set_nt_config(int cfg) {
     g_nt_cfg_override = cfg;
@@ -526,13 +988,16 @@ static int pick_nt_cfg(int M, int N) {
     // measured on the ViT-B/16 shapes: 256x256 tiles win (1.2-1.3x over 128x128) once they fill the
     // 256 CUs at least once; 256x128 never wins
     const long long tiles = (long long)ceil_div(M, 256) * ceil_div(N, 256);
-    return tiles >= 256 ? 2 : 0;
+    return tiles >= 256 ? 3 : 0;  // 3 falls back to 2 when K % 64 != 0
 }
 
 template <int EPI, typename OutT, bool PATCH>
 static int launch_nt_epi(int M, int N, int K, const bf16_t* a, long long lda, const bf16_t* b, long long ldb,
                          const FastEpi& e, const PatchGeom& pg, hipStream_t s) {
     switch (pick_nt_cfg(M, N)) {
+        case 3:
+            if (!PATCH && K % TK == 0 && K > 0) return launch_nt_phased<EPI, OutT>(M, N, K, a, lda, b, ldb, e, s);
+            [[fallthrough]];
         case 2: return launch_nt_cfg<EPI, OutT, PATCH, 256, 256, 2, 4>(M, N, K, a, lda, b, ldb, e, pg, s);
         case 1: return launch_nt_cfg<EPI, OutT, PATCH, 256, 128, 4, 2>(M, N, K, a, lda, b, ldb, e, pg, s);
         default: return launch_nt_cfg<EPI, OutT, PATCH, 128, 128, 2, 2>(M, N, K, a, lda, b, ldb, e, pg, s);
@@ -580,7 +1045,7 @@ bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const voi
     return !(P % 8 || Q % 8 || ldu % 8 || ldv % 8 || ldc % 4 || !al16(U) || !al16(V) || !al16(C));
 }
 
-// tile configuration of the tn kernel: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves)
+// tile configuration of the tn kernel: 0 = 128x128 (4 waves), 1 = 256x256 (8 waves), 2 = 256x256 phased
 static int g_tn_cfg_override = -1;
 extern "C" int vitmi_debug_set_tn_config(int cfg) {
     g_tn_cfg_override = cfg;
@@ -588,16 +1053,16 @@ extern "C" int vitmi_debug_set_tn_config(int cfg) {
 }
 static int pick_tn_cfg(int P, int Q) {
     if (g_tn_cfg_override >= 0) return g_tn_cfg_override;
-    return (P >= 512 && Q >= 512) ? 1 : 0;
+    return (P >= 512 && Q >= 512) ? 2 : 0;  // 2 falls back to 1 when T % 64 != 0
 }
 
 // number of t-slabs the tn kernel would use (the caller sizes the workspace from it)
 int vitmi_gemm_tn_slabs(int P, int Q, int T) {
     const int cfg = pick_tn_cfg(P, Q);
-    const int bt = cfg == 1 ? 256 : 128;
+    const int bt = cfg >= 1 ? 256 : 128;
     const int tiles = ceil_div(P, bt) * ceil_div(Q, bt);
     const int nk = ceil_div(T, TK);
-    const int target = cfg == 1 ? 256 : 512;  // resident blocks on 256 CUs
+    const int target = cfg >= 1 ? 256 : 512;  // resident blocks on 256 CUs
     int s = (target + tiles - 1) / tiles;
     if (s > nk) s = nk;
     if (s > 32) s = 32;
@@ -637,11 +1102,39 @@ static int launch_tn_cfg(int P, int Q, int T, const void* U, long long ldu, cons
     return VITMI_OK;
 }
 
+static int launch_tn_phased(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
+                            long long ldc, float* slabs, int ns, hipStream_t s) {
+    static unsigned long long done = 0;
+    constexpr size_t lds = 2 * 4 * (size_t)TK * 128 * sizeof(bf16_t);
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(gemm_tn_phased_kernel), lds, &done);
+    if (rc != VITMI_OK) return rc;
+    const int tiles_p = ceil_div(P, 256), tiles_q = ceil_div(Q, 256);
+    if (!slabs) ns = 1;
+    const int nk = T / TK;
+    const int per = ceil_div(nk, ns);
+    ns = ceil_div(nk, per);
+    dim3 grid(tiles_p * tiles_q * ns), block(512);
+    const bool direct = (ns == 1);
+    const long long slab_stride = direct ? 0ll : (long long)P * ldc;
+    hipLaunchKernelGGL(gemm_tn_phased_kernel, grid, block, lds, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
+                       direct ? C : slabs, ldc, slab_stride, P, Q, tiles_q, tiles_p * tiles_q, per, nk);
+    VITMI_LAUNCH_CHECK("vitmi_gemm(tn phased)");
+    if (!direct) {
+        const long long n4 = slab_stride / 4;
+        int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, s, slabs, slab_stride, ns, C, n4);
+        VITMI_LAUNCH_CHECK("vitmi_gemm(tn reduce)");
+    }
+    return VITMI_OK;
+}
+
 template <bool PATCH>
 static int launch_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
                           long long ldc, float* slabs, const PatchGeom& pg, hipStream_t s) {
     const int ns = vitmi_gemm_tn_slabs(P, Q, T);
-    if (pick_tn_cfg(P, Q) == 1)
+    if (!PATCH && pick_tn_cfg(P, Q) == 2 && T % TK == 0 && T > 0)
+        return launch_tn_phased(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, s);
+    if (pick_tn_cfg(P, Q) >= 1)
         return launch_tn_cfg<PATCH, 256, 256, 2, 4>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s);
     return launch_tn_cfg<PATCH, 128, 128, 2, 2>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s);
 }
