@@ -1062,8 +1062,10 @@ int vitmi_gemm_tn_slabs(int P, int Q, int T) {
     const int bt = cfg >= 1 ? 256 : 128;
     const int tiles = ceil_div(P, bt) * ceil_div(Q, bt);
     const int nk = ceil_div(T, TK);
-    const int target = cfg >= 1 ? 256 : 512;  // resident blocks on 256 CUs
-    int s = (target + tiles - 1) / tiles;
+    // blocks that are resident at once on 256 CUs; rounding DOWN keeps the launch to one round of
+    // blocks (one block more than the chip holds would double the kernel's time)
+    const int target = cfg >= 1 ? 256 : 512;
+    int s = target / tiles;
     if (s > nk) s = nk;
     if (s > 32) s = 32;
     if (s < 1) s = 1;
