@@ -177,6 +177,27 @@ int vitmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     long long n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                     float grad_scale, void* stream);
 
+/* The same update for many tensors in ONE launch (torch.optim.Adam walks its parameter list,
+ * trainer.py:204-205; a ViT-B/16 has ~150 parameter tensors, most of them tiny).
+ * tensors (device memory) holds n_tensors records; chunks (device memory) holds n_chunks pairs
+ * {tensor index, first element}: block c updates elements [first, first + chunk_elems) of its
+ * tensor, clipped to the tensor's n.  chunk_elems must be a positive multiple of 4. */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    void* param_bf16; /* may be NULL */
+    long long n;
+} vitmi_adam_tensor;
+typedef struct {
+    long long tensor;
+    long long first;
+} vitmi_adam_chunk;
+int vitmi_adam_step_multi(const vitmi_adam_tensor* tensors, int n_tensors, const vitmi_adam_chunk* chunks,
+                          int n_chunks, int chunk_elems, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

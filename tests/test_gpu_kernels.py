@@ -292,3 +292,27 @@ def test_fast_weight_gradient_gemm(ops, T, P, Q):
     assert rel_err(dw, ref) < 1e-4                      # fp32 accumulation of exact bf16 products
     dw2 = ops.linear_bwd_w(dy.to(DEV, dtype), x.to(DEV, dtype))
     assert torch.equal(dw, dw2)                         # slab order is fixed: bitwise reproducible
+
+
+# ------------------------------------------------------------------------------------------ optimizer
+def test_fused_adam_matches_torch_adam(ops):
+    """One-launch multi-tensor Adam against torch.optim.Adam (trainer.py:204-205 settings) on tensors
+    that are smaller than, equal to and larger than a chunk, with sizes not divisible by 4."""
+    from visiontransformer_amd.optim import CHUNK, FusedAdam
+    shapes = [(7,), (1, 1, 3), (CHUNK,), (CHUNK + 5,), (3, CHUNK // 2 + 1), (768, 96)]
+    ref_p = [torch.nn.Parameter(rnd(*s, seed=40 + i)) for i, s in enumerate(shapes)]
+    our_p = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    kw = dict(lr=1e-3, betas=(0.9, 0.99), weight_decay=5e-5)
+    ref_opt, our_opt = torch.optim.Adam(ref_p, **kw), FusedAdam(our_p, **kw)
+    # a bf16 compute copy that the kernel must keep in step with the master weights
+    w16 = ops.compute_copy(our_p[-1], torch.bfloat16)
+    for step in range(3):
+        for i, (a, b) in enumerate(zip(ref_p, our_p)):
+            g = rnd(*a.shape, seed=100 + 10 * step + i)
+            a.grad, b.grad = g, g.to(DEV)
+        ref_opt.step()
+        our_opt.step()
+    for a, b in zip(ref_p, our_p):
+        assert rel_err(b, a.detach()) < 1e-6
+    assert ops.compute_copy(our_p[-1], torch.bfloat16) is w16
+    assert torch.equal(w16.cpu(), our_p[-1].detach().cpu().to(torch.bfloat16))

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vitmi_meanpool_bwd": (I, [P, P, I, I, I, I, P]),
     "vitmi_add": (I, [P, P, P, I, L, P]),
     "vitmi_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, F, I, F, P]),
+    "vitmi_adam_step_multi": (I, [P, I, P, I, I, F, F, F, F, F, I, F, P]),
 }
 
 

@@ -454,6 +454,72 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+__device__ __forceinline__ void adam_update(float& pi, float gi, float& mi, float& vi, float lr_c, float b1, float b2,
+                                            float eps, float wd, float bc2_sqrt, float gscale) {
+    gi *= gscale;
+    if (wd != 0.f) gi += wd * pi;
+    mi = b1 * mi + (1.f - b1) * gi;
+    vi = b2 * vi + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi -= lr_c * (mi / denom);
+}
+
+// one block per chunk of one tensor; 16-byte accesses on the aligned body
+__global__ __launch_bounds__(256) void adam_multi_kernel(const vitmi_adam_tensor* __restrict__ tensors,
+                                                         const vitmi_adam_chunk* __restrict__ chunks, int chunk_elems,
+                                                         float lr_c, float b1, float b2, float eps, float wd,
+                                                         float bc2_sqrt, float gscale) {
+    const vitmi_adam_chunk ck = chunks[blockIdx.x];
+    const vitmi_adam_tensor t = tensors[ck.tensor];
+    const long long end = ck.first + chunk_elems < t.n ? ck.first + chunk_elems : t.n;
+    float* __restrict__ p = t.param;
+    const float* __restrict__ g = t.grad;
+    float* __restrict__ m = t.exp_avg;
+    float* __restrict__ v = t.exp_avg_sq;
+    bf16_t* __restrict__ p16 = (bf16_t*)t.param_bf16;
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                       reinterpret_cast<uintptr_t>(v)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(p16) & 7) == 0;
+    auto scalar = [&](long long k) {
+        float a = p[k], b = m[k], c = v[k];
+        adam_update(a, g[k], b, c, lr_c, b1, b2, eps, wd, bc2_sqrt, gscale);
+        p[k] = a;
+        m[k] = b;
+        v[k] = c;
+        if (p16) p16[k] = (bf16_t)a;
+    };
+    if (!vec) {  // unaligned tensor
+        for (long long k = ck.first + threadIdx.x; k < end; k += 256) scalar(k);
+        return;
+    }
+    for (long long i = ck.first + 4ll * threadIdx.x; i + 4 <= end; i += 4 * 256) {
+        f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+        f32x4 mv = *reinterpret_cast<const f32x4*>(m + i);
+        f32x4 vv = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a = pv[k], b = mv[k], c = vv[k];
+            adam_update(a, gv[k], b, c, lr_c, b1, b2, eps, wd, bc2_sqrt, gscale);
+            pv[k] = a;
+            mv[k] = b;
+            vv[k] = c;
+        }
+        *reinterpret_cast<f32x4*>(p + i) = pv;
+        *reinterpret_cast<f32x4*>(m + i) = mv;
+        *reinterpret_cast<f32x4*>(v + i) = vv;
+        if (p16) {
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (bf16_t)pv[k];
+            *reinterpret_cast<bf16x4*>(p16 + i) = o;
+        }
+    }
+    // the last 1-3 elements of the tensor
+    const long long k = ck.first + ((end - ck.first) & ~3ll) + threadIdx.x;
+    if (k < end) scalar(k);
+}
+
 }  // namespace
 
 // ================================================================ C ABI
@@ -727,5 +793,21 @@ extern "C" int vitmi_adam_step(float* param, const float* grad, float* exp_avg, 
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq,
                        (bf16_t*)param_bf16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
     VITMI_LAUNCH_CHECK("vitmi_adam_step");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_adam_step_multi(const vitmi_adam_tensor* tensors, int n_tensors, const vitmi_adam_chunk* chunks,
+                                     int n_chunks, int chunk_elems, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, int step, float grad_scale, void* stream) {
+    VITMI_CHECK_ARG(n_tensors >= 0 && n_chunks >= 0 && step >= 1, "vitmi_adam_step_multi: bad argument");
+    VITMI_CHECK_ARG(chunk_elems > 0 && chunk_elems % 4 == 0, "vitmi_adam_step_multi: chunk_elems must be a positive multiple of 4");
+    if (n_chunks == 0) return VITMI_OK;
+    VITMI_CHECK_ARG(tensors && chunks && n_tensors > 0, "vitmi_adam_step_multi: null table");
+    hipStream_t s = as_stream(stream);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, s, tensors, chunks, chunk_elems, lr / bc1, beta1,
+                       beta2, eps, weight_decay, bc2_sqrt, grad_scale);
+    VITMI_LAUNCH_CHECK("vitmi_adam_step_multi");
     return VITMI_OK;
 }

@@ -4,6 +4,8 @@ Every function here moves raw device pointers, shapes and the current HIP stream
 boundary; tensors are allocated by PyTorch's caching allocator.  There is no CPU or eager
 fallback: CPU tensors raise.
 """
+import weakref
+
 import torch
 
 from . import _lib
@@ -56,17 +58,36 @@ def cast(t, dtype):
     return out
 
 
+def _cache_lookup(key, param):
+    """The cached copy for `key` if it was made from this very tensor object at its current version
+    and storage (id() values are recycled once a tensor dies, hence the weak reference)."""
+    hit = _cast_cache.get(key)
+    if hit is None:
+        return None
+    ver, ptr, copy, ref = hit
+    if ref() is param and ver == param._version and ptr == param.data_ptr() and copy.device == param.device:
+        return copy
+    return None
+
+
+def _cache_store(key, param, copy):
+    def _drop(_ref, key=key):
+        ent = _cast_cache.get(key)
+        if ent is not None and ent[3] is _ref:
+            del _cast_cache[key]
+    _cast_cache[key] = (param._version, param.data_ptr(), copy, weakref.ref(param, _drop))
+
+
 def compute_copy(param, dtype):
     """A `dtype` copy of parameter `param`, cached until the parameter is next modified in place."""
     if param.dtype == dtype:
         return param.detach()
     key = (id(param), dtype)
-    hit = _cast_cache.get(key)
-    ver = param._version
-    if hit is not None and hit[0] == ver and hit[1] == param.data_ptr() and hit[2].device == param.device:
-        return hit[2]
+    hit = _cache_lookup(key, param)
+    if hit is not None:
+        return hit
     c = cast(param, dtype)
-    _cast_cache[key] = (ver, param.data_ptr(), c)
+    _cache_store(key, param, c)
     return c
 
 
@@ -74,16 +95,15 @@ def compute_copy_t(param, dtype):
     """Transposed compute copy of a 2-D weight: [K, N] for a parameter stored [N, K].  bf16 only
     (the fp32 kernels read the weight through strides instead)."""
     key = (id(param), dtype, "T")
-    hit = _cast_cache.get(key)
-    ver = param._version
-    if hit is not None and hit[0] == ver and hit[1] == param.data_ptr() and hit[2].device == param.device:
-        return hit[2]
+    hit = _cache_lookup(key, param)
+    if hit is not None:
+        return hit
     _need_gpu(param)
     src = param.detach().contiguous()
     n, k = src.shape
     out = torch.empty((k, n), dtype=dtype, device=src.device)
     check(lib.vitmi_transpose_cast(_p(src), _dt(src), _p(out), n, k, _stream()), "vitmi_transpose_cast")
-    _cast_cache[key] = (ver, param.data_ptr(), out)
+    _cache_store(key, param, out)
     return out
 
 

@@ -1,9 +1,16 @@
 """Fused Adam over fp32 master parameters (torch.optim.Adam semantics, the optimizer of
-trainer.py:204-205) that refreshes the bf16 compute copies of the weights in the same pass."""
+trainer.py:204-205) that refreshes the bf16 compute copies of the weights in the same pass.
+
+One launch updates every parameter tensor: a table of (param, grad, exp_avg, exp_avg_sq, bf16 copy, n)
+records and a table of (tensor, first element) chunks are uploaded each step (gradient buffers
+may move between steps) and `vitmi_adam_step_multi` gives one block to each chunk."""
+import numpy as np
 import torch
 
 from . import ops
 from ._lib import check, lib
+
+CHUNK = 65536  # elements per block
 
 
 class FusedAdam:
@@ -12,6 +19,7 @@ class FusedAdam:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.state = {}
+        self._tables = {}   # device -> (pinned host buffers, device buffer, copy-done events, parity)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -20,28 +28,66 @@ class FusedAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
+    def _state(self, p):
+        st = self.state.get(p)
+        if st is None:
+            st = (torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32))
+            self.state[p] = st
+        return st
+
+    def _upload(self, device, words):
+        """Stream-ordered upload of an int64 table through one of two pinned staging buffers."""
+        n = len(words)
+        ent = self._tables.get(device)
+        if ent is None or ent[0][0].numel() < n:
+            cap = max(2 * n, 1024)
+            host = [torch.empty(cap, dtype=torch.int64).pin_memory() for _ in range(2)]
+            dev = torch.empty(cap, dtype=torch.int64, device=device)
+            ent = [host, dev, [None, None], 0]
+            self._tables[device] = ent
+        host, dev, events, parity = ent
+        if events[parity] is not None:
+            events[parity].synchronize()      # the copy that last read this staging buffer has finished
+        host[parity][:n].copy_(torch.from_numpy(words))
+        dev[:n].copy_(host[parity][:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        events[parity] = ev
+        ent[3] = parity ^ 1
+        return dev
+
     @torch.no_grad()
     def step(self, grad_scale=1.0):
         self.step_count += 1
-        stream = torch.cuda.current_stream().cuda_stream
+        by_device = {}
         for p in self.params:
-            g = p.grad
-            if g is None:
+            if p.grad is None:
                 continue
             if not p.is_cuda:
                 raise RuntimeError("FusedAdam runs on ROCm device tensors only")
-            st = self.state.get(p)
-            if st is None:
-                st = (torch.zeros_like(p, dtype=torch.float32), torch.zeros_like(p, dtype=torch.float32))
-                self.state[p] = st
-            g = g.contiguous()
-            hit = ops._cast_cache.get((id(p), torch.bfloat16))
-            p16 = None
-            if hit is not None and hit[0] == p._version and hit[1] == p.data_ptr():
-                p16 = hit[2]
-            # the transposed copy cannot be refreshed in the same pass: drop it, it is rebuilt on use
-            ops._cast_cache.pop((id(p), torch.bfloat16, "T"), None)
-            check(lib.vitmi_adam_step(p.data_ptr(), g.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
-                                      p16.data_ptr() if p16 is not None else None, p.numel(), self.lr, self.betas[0],
-                                      self.betas[1], self.eps, self.weight_decay, self.step_count, grad_scale, stream),
-                  "vitmi_adam_step")
+            by_device.setdefault(p.device, []).append(p)
+        for device, plist in by_device.items():
+            recs, chunks, keep = [], [], []
+            for ti, p in enumerate(plist):
+                g = p.grad.contiguous()
+                if g.dtype != torch.float32:
+                    g = g.float()
+                keep.append(g)
+                m, v = self._state(p)
+                hit = ops._cache_lookup((id(p), torch.bfloat16), p)
+                p16 = hit.data_ptr() if hit is not None else 0
+                # the transposed copy cannot be refreshed in the same pass: drop it, it is rebuilt on use
+                ops._cast_cache.pop((id(p), torch.bfloat16, "T"), None)
+                n = p.numel()
+                recs.extend((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p16, n))
+                for first in range(0, n, CHUNK):
+                    chunks.extend((ti, first))
+            words = np.asarray(recs + chunks, dtype=np.int64)
+            with torch.cuda.device(device):
+                dev = self._upload(device, words)
+                stream = torch.cuda.current_stream().cuda_stream
+                check(lib.vitmi_adam_step_multi(dev.data_ptr(), len(plist), dev.data_ptr() + 8 * len(recs),
+                                                len(chunks) // 2, CHUNK, self.lr, self.betas[0], self.betas[1],
+                                                self.eps, self.weight_decay, self.step_count, grad_scale, stream),
+                      "vitmi_adam_step_multi")
+            del keep
