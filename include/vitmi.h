@@ -82,6 +82,18 @@ int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long sam, long l
                long long sbn, long long sbk, void* C, long long ldc, int c_dt, int epilogue, const float* bias,
                const void* residual, long long ldr, void* aux, long long ldaux, void* stream);
 
+/* vitmi_gemm that also returns colsum[n] = sum_m of the values it writes to C[:, n] (fp32, N
+ * entries): with the dGELU epilogue this is the bias gradient of the first MLP layer
+ * (autograd of nn.Linear + nn.GELU, mymodel/ViT.py:66-67) without a second pass over the
+ * [tokens, mlp_dim] gradient.  On the large aligned shapes the sums come out of the GEMM
+ * epilogue (per 128-row partial sums, reduced in a fixed order); otherwise a column-sum kernel
+ * runs over C.  workspace: vitmi_gemm_colsum_workspace_bytes(M, N) bytes. */
+long long vitmi_gemm_colsum_workspace_bytes(int M, int N);
+int vitmi_gemm_colsum(int dt, int M, int N, int K, const void* A, long long sam, long long sak, const void* B,
+                      long long sbn, long long sbk, void* C, long long ldc, int c_dt, int epilogue,
+                      const float* bias, const void* residual, long long ldr, void* aux, long long ldaux,
+                      float* colsum, void* workspace, void* stream);
+
 /* Weight gradient C[p][q] (fp32, row stride ldc) = sum_t U[t][p] * V[t][q]: U is [T,P] (row
  * stride ldu), V is [T,Q] (row stride ldv), both `dt`.  For y = x W^T: dW = wgrad(U = dy, V = x).
  * The contraction over tokens is split into slabs summed in a fixed order (deterministic);

@@ -279,6 +279,13 @@ def test_fast_nt_gemm_all_epilogues(ops, M, N, K):
     a = aux.float().cpu().requires_grad_(True)
     vit_oracle.gelu_erf(a).backward(q(dy, dtype) @ q(w, dtype))
     assert rel_err(du, a.grad) < 1e-2
+    # the same product with the column sums of its result (bias gradient of the layer below) from one call
+    du2, cs = ops.linear_bwd_x(dy.to(DEV, dtype), wd, epi=ops.EPI_DGELU, aux=aux, w_t=wt, want_colsum=True)
+    assert torch.equal(du2, du)
+    assert rel_err(cs, a.grad.sum(0)) < 1e-2
+    assert rel_err(cs, du.float().sum(0)) < 2e-3          # sums of the unrounded values vs sums of bf16
+    _, cs2 = ops.linear_bwd_x(dy.to(DEV, dtype), wd, epi=ops.EPI_DGELU, aux=aux, w_t=wt, want_colsum=True)
+    assert torch.equal(cs, cs2)                            # fixed summation order
 
 
 # T % 64 == 0 with P, Q >= 512 takes the phased kernel (ragged P and Q edges, one and two token tiles)

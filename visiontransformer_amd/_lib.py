@@ -27,6 +27,8 @@ SIGNATURES = {
     "vitmi_prof_name": (c_char_p, [I]),
     "vitmi_cast": (I, [P, I, P, I, L, P]),
     "vitmi_gemm": (I, [I, I, I, I, P, L, L, P, L, L, P, L, I, I, P, P, L, P, L, P]),
+    "vitmi_gemm_colsum_workspace_bytes": (L, [I, I]),
+    "vitmi_gemm_colsum": (I, [I, I, I, I, P, L, L, P, L, L, P, L, I, I, P, P, L, P, L, P, P, P]),
     "vitmi_gemm_wgrad_workspace_bytes": (L, [I, I, I, I]),
     "vitmi_gemm_wgrad": (I, [I, I, I, I, P, L, P, L, P, L, P, P]),
     "vitmi_transpose_cast": (I, [P, I, P, I, I, P]),

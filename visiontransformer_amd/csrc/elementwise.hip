@@ -569,6 +569,14 @@ extern "C" int vitmi_add(const void* a, const void* b, void* y, int dt, long lon
 extern "C" long long vitmi_colsum_workspace_bytes(long long rows, int cols) {
     return (long long)colsum_chunks(rows) * cols * (long long)sizeof(float);
 }
+long long vitmi_colsum_workspace_bytes_impl(long long rows, int cols) { return vitmi_colsum_workspace_bytes(rows, cols); }
+
+// out[c] = sum over the `chunks` rows of a dense [chunks][cols] fp32 partial matrix, fixed order
+int vitmi_colsum_final_launch(const float* partial, int chunks, int cols, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 64)), dim3(1024), 0, s, partial, chunks, cols, out);
+    VITMI_LAUNCH_CHECK("colsum(final)");
+    return VITMI_OK;
+}
 
 extern "C" int vitmi_colsum(const void* x, int dt, long long rows, int cols, long long ld, float* out, void* workspace,
                             void* stream) {

@@ -20,7 +20,11 @@ bool vitmi_gemm_nt_fast_ok(int M, int N, int K, const void* A, long long lda, co
                            long long ldaux);
 int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
                        long long ldc, int c_dt, int epilogue, const float* bias, const void* residual, long long ldr,
-                       void* aux, long long ldaux, hipStream_t s);
+                       void* aux, long long ldaux, float* cs_partial, hipStream_t s);
+bool vitmi_gemm_nt_phased_ok(int M, int N, int K);
+int vitmi_gemm_nt_colsum_rows(int M);
+int vitmi_colsum_final_launch(const float* partial, int chunks, int cols, float* out, hipStream_t s);
+long long vitmi_colsum_workspace_bytes_impl(long long rows, int cols);
 bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const void* V, long long ldv, const void* C,
                            long long ldc);
 int vitmi_gemm_tn_slabs(int P, int Q, int T);
@@ -353,10 +357,10 @@ void dispatch_bf16_layout(bool a_kc, bool b_kc, const void* A, long long sam, lo
 
 }  // namespace
 
-extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long sam, long long sak, const void* B,
-                          long long sbn, long long sbk, void* C, long long ldc, int c_dt, int epilogue,
-                          const float* bias, const void* residual, long long ldr, void* aux, long long ldaux,
-                          void* stream) {
+// cs_partial != nullptr asks the phased nt kernel (the caller checked that it will run) for column sums
+static int gemm_impl(int dt, int M, int N, int K, const void* A, long long sam, long long sak, const void* B,
+                     long long sbn, long long sbk, void* C, long long ldc, int c_dt, int epilogue, const float* bias,
+                     const void* residual, long long ldr, void* aux, long long ldaux, float* cs_partial, void* stream) {
     VITMI_CHECK_ARG(A && B && C, "vitmi_gemm: null operand");
     VITMI_CHECK_ARG(M > 0 && N > 0 && K > 0, "vitmi_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     VITMI_CHECK_ARG(ldc >= N, "vitmi_gemm: ldc=%lld < N=%d", ldc, N);
@@ -381,7 +385,8 @@ extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long 
     }
     ProfScope prof(fam, s, 2.0 * M * N * K);
     if (fast_nt)
-        return vitmi_gemm_nt_fast(M, N, K, A, sam, B, sbn, C, ldc, c_dt, epilogue, bias, residual, ldr, aux, ldaux, s);
+        return vitmi_gemm_nt_fast(M, N, K, A, sam, B, sbn, C, ldc, c_dt, epilogue, bias, residual, ldr, aux, ldaux,
+                                  cs_partial, s);
     if (dt == VITMI_F32) {
         VITMI_CHECK_ARG(c_dt == VITMI_F32, "vitmi_gemm: fp32 compute writes fp32 output");
         F32Operand a{(const float*)A, sam, sak, M, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -410,6 +415,41 @@ extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long 
         dispatch_bf16_layout<VITMI_EPI_DGELU, bf16_t>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
     VITMI_LAUNCH_CHECK("vitmi_gemm(bf16)");
     return VITMI_OK;
+}
+
+extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long sam, long long sak, const void* B,
+                          long long sbn, long long sbk, void* C, long long ldc, int c_dt, int epilogue,
+                          const float* bias, const void* residual, long long ldr, void* aux, long long ldaux,
+                          void* stream) {
+    return gemm_impl(dt, M, N, K, A, sam, sak, B, sbn, sbk, C, ldc, c_dt, epilogue, bias, residual, ldr, aux, ldaux,
+                     nullptr, stream);
+}
+
+extern "C" long long vitmi_gemm_colsum_workspace_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    const long long fused = (long long)vitmi_gemm_nt_colsum_rows(M) * N * (long long)sizeof(float);
+    const long long separate = vitmi_colsum_workspace_bytes_impl(M, N);
+    return fused > separate ? fused : separate;
+}
+
+extern "C" int vitmi_gemm_colsum(int dt, int M, int N, int K, const void* A, long long sam, long long sak,
+                                 const void* B, long long sbn, long long sbk, void* C, long long ldc, int c_dt,
+                                 int epilogue, const float* bias, const void* residual, long long ldr, void* aux,
+                                 long long ldaux, float* colsum, void* workspace, void* stream) {
+    VITMI_CHECK_ARG(colsum && workspace, "vitmi_gemm_colsum: null colsum or workspace");
+    VITMI_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "vitmi_gemm_colsum: bad operands");
+    hipStream_t s = as_stream(stream);
+    const bool fused = dt == VITMI_BF16 && c_dt == VITMI_BF16 && epilogue == VITMI_EPI_DGELU && sak == 1 && sbk == 1 &&
+                       vitmi_gemm_nt_fast_ok(M, N, K, A, sam, B, sbn, C, ldc, c_dt, residual, ldr, aux, ldaux) &&
+                       vitmi_gemm_nt_phased_ok(M, N, K);
+    int rc = gemm_impl(dt, M, N, K, A, sam, sak, B, sbn, sbk, C, ldc, c_dt, epilogue, bias, residual, ldr, aux, ldaux,
+                       fused ? (float*)workspace : nullptr, stream);
+    if (rc != VITMI_OK) return rc;
+    if (fused) {
+        ProfScope prof(VITMI_FAM_OTHER, s, 0.0);
+        return vitmi_colsum_final_launch((const float*)workspace, vitmi_gemm_nt_colsum_rows(M), N, colsum, s);
+    }
+    return vitmi_colsum(C, c_dt, M, N, ldc, colsum, workspace, stream);
 }
 
 extern "C" int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, const float* bias, void* out, int dt,

@@ -102,6 +102,7 @@ struct FastEpi {
     long long ldaux;
     int rows_per_group;      // > 0: row m lives at C + (m / rpg) * group_stride + (m % rpg) * ldc
     long long group_stride;
+    float* cs_partial;       // phased kernel only: [2 * m-tiles][N] column sums of the stored values
 };
 
 // v[t] belongs to row m, column n + (t & 7) + (t >> 3) * H2: two runs of 8 consecutive columns, H2
@@ -323,7 +324,7 @@ __device__ __forceinline__ void wait_vm_regions(int pend) {  // 2 loads per wave
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EPI, typename OutT>
+template <int EPI, typename OutT, bool CS>
 __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __restrict__ A, long long lda,
                                                              const bf16_t* __restrict__ B, long long ldb,
                                                              FastEpi epi, int M, int N, int K, int tiles_n,
@@ -490,8 +491,16 @@ __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __res
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();  // matches the second group's extra barrier
 
+    float cs[CS ? 16 : 1];
+    if (CS) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) cs[t] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+        // with the column sums the register file is full here: keep hipcc from hoisting the operand
+        // loads of all eight row groups to the top (a spill's reload would wait for the tile's stores)
+        if (CS && (i & 1) == 0) __builtin_amdgcn_sched_barrier(0);
         const int m = m0 + wr * 128 + i * 16 + fr;
         const int n = n0 + wc * 64 + 8 * fg;
         if (m < M && n < N) {
@@ -501,6 +510,41 @@ __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __res
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[j][i][r];
             epi_row16<EPI, OutT, 32>(epi, m, n, N, v);
+            if (CS) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) cs[t] += v[t];
+            }
+        }
+    }
+    if (CS) {
+        // column sums of this wave's 128 rows: the 16 row lanes of a column group combine in a fixed
+        // butterfly order, lane fr == 0 writes row (2 * m-tile + wr) of the partial matrix
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            float x = cs[t];
+            x += __shfl_xor(x, 1, 64);
+            x += __shfl_xor(x, 2, 64);
+            x += __shfl_xor(x, 4, 64);
+            x += __shfl_xor(x, 8, 64);
+            cs[t] = x;
+        }
+        const int n = n0 + wc * 64 + 8 * fg;
+        if (fr == 0) {
+            float* prow = epi.cs_partial + (long long)((m0 >> 8) * 2 + wr) * N + n;
+            if (n + 40 <= N && (N & 3) == 0) {
+#pragma unroll
+                for (int t4 = 0; t4 < 4; ++t4)
+                    *reinterpret_cast<f32x4*>(prow + (t4 & 1) * 4 + (t4 >> 1) * 32) =
+                        f32x4{cs[4 * t4], cs[4 * t4 + 1], cs[4 * t4 + 2], cs[4 * t4 + 3]};
+            } else {
+                for (int t = 0; t < 16; ++t) {
+                    const int c = (t & 7) + (t >> 3) * 32;
+                    float x = cs[0];
+#pragma unroll
+                    for (int u = 1; u < 16; ++u) x = (t == u) ? cs[u] : x;
+                    if (n + c < N) prow[c] = x;
+                }
+            }
         }
     }
     }  // tile loop
@@ -963,13 +1007,27 @@ static int launch_nt_phased(int M, int N, int K, const bf16_t* a, long long lda,
                             const FastEpi& e, hipStream_t s) {
     static unsigned long long done = 0;
     constexpr size_t lds = 2 * 4 * (size_t)RG * sizeof(bf16_t);
-    auto fn = gemm_nt_phased_kernel<EPI, OutT>;
-    int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
-    if (rc != VITMI_OK) return rc;
     const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 256);
     const int ntiles = tiles_m * tiles_n;
     int grid = ntiles;
     if (grid > phased_grid_blocks()) grid = phased_grid_blocks();
+    if (e.cs_partial) {
+        // column sums are produced by the one instantiation that needs them (dGELU -> bf16)
+        if (EPI != VITMI_EPI_DGELU || sizeof(OutT) != 2) {
+            vitmi_set_error("vitmi_gemm(nt phased): column sums are only fused into the dGELU epilogue");
+            return VITMI_ERR_BAD_ARG;
+        }
+        static unsigned long long done_cs = 0;
+        auto fcs = gemm_nt_phased_kernel<VITMI_EPI_DGELU, bf16_t, true>;
+        int rc = ensure_lds_attr(reinterpret_cast<const void*>(fcs), lds, &done_cs);
+        if (rc != VITMI_OK) return rc;
+        hipLaunchKernelGGL(fcs, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles);
+        VITMI_LAUNCH_CHECK("vitmi_gemm(nt phased + column sums)");
+        return VITMI_OK;
+    }
+    auto fn = gemm_nt_phased_kernel<EPI, OutT, false>;
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
+    if (rc != VITMI_OK) return rc;
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles);
     VITMI_LAUNCH_CHECK("vitmi_gemm(nt phased)");
     return VITMI_OK;
@@ -1017,10 +1075,15 @@ static int launch_nt_fast(int M, int N, int K, const void* A, long long lda, con
     return launch_nt_epi<VITMI_EPI_DGELU, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
 }
 
+// true when vitmi_gemm_nt_fast would run the phased kernel, the one that can also emit column sums;
+// rows of the partial matrix it then writes: 2 per 256-row tile
+bool vitmi_gemm_nt_phased_ok(int M, int N, int K) { return pick_nt_cfg(M, N) == 3 && K % TK == 0 && K > 0; }
+int vitmi_gemm_nt_colsum_rows(int M) { return 2 * ceil_div(M, 256); }
+
 int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
                        long long ldc, int c_dt, int epilogue, const float* bias, const void* residual, long long ldr,
-                       void* aux, long long ldaux, hipStream_t s) {
-    FastEpi e{C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)aux, ldaux, 0, 0};
+                       void* aux, long long ldaux, float* cs_partial, hipStream_t s) {
+    FastEpi e{C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)aux, ldaux, 0, 0, cs_partial};
     return launch_nt_fast<false>(M, N, K, A, lda, B, ldb, e, c_dt, epilogue, PatchGeom{}, s);
 }
 
@@ -1036,7 +1099,7 @@ int vitmi_patch_fwd_fast(const void* img, const void* w, const float* bias, void
                          int p, int D, long long out_batch_stride, hipStream_t s) {
     const int gh = H / p, gw = W / p, per = gh * gw, E = C * p * p;
     PatchGeom pg{C, H, W, p, gw, per, B * per, E};
-    FastEpi e{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride};
+    FastEpi e{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride, nullptr};
     return launch_nt_fast<true>(B * per, D, E, img, 0, w, E, e, VITMI_BF16, VITMI_EPI_NONE, pg, s);
 }
 

@@ -134,12 +134,22 @@ def linear_fwd(x2, w, bias=None, res=None, epi=EPI_NONE, want_aux=False, out_dty
     return y, aux
 
 
-def linear_bwd_x(dy2, w, epi=EPI_NONE, aux=None, w_t=None):
+def linear_bwd_x(dy2, w, epi=EPI_NONE, aux=None, w_t=None, want_colsum=False):
     """dx[T,K] = dy2[T,N] @ w[N,K]   (optionally times gelu'(aux)).  With w_t = w^T stored [K,N]
-    the product runs in the k-contiguous form."""
+    the product runs in the k-contiguous form.  want_colsum also returns the fp32 column sums of
+    dx (the bias gradient of the layer below) from the same launch."""
     T, N = dy2.shape
     K = w.shape[1] if w_t is None else w_t.shape[0]
     dx = torch.empty((T, K), dtype=dy2.dtype, device=dy2.device)
+    if want_colsum:
+        _need_gpu(dy2)
+        cs = torch.empty((K,), dtype=torch.float32, device=dy2.device)
+        ws = _ws(lib.vitmi_gemm_colsum_workspace_bytes(T, K), dy2.device)
+        b, sbn, sbk = (w_t, w_t.stride(0), 1) if w_t is not None else (w, 1, w.stride(0))
+        check(lib.vitmi_gemm_colsum(_dt(dy2), T, K, N, _p(dy2), dy2.stride(0), 1, _p(b), sbn, sbk, _p(dx), K, _dt(dx),
+                                    epi, None, None, 0, _p(aux) if aux is not None else None,
+                                    K if aux is not None else 0, _p(cs), _p(ws), _stream()), "vitmi_gemm_colsum")
+        return dx, cs
     if w_t is not None:
         gemm_raw(_dt(dy2), T, K, N, dy2, dy2.stride(0), 1, w_t, w_t.stride(0), 1, dx, K, _dt(dx), epi, None, None, 0,
                  aux, K if aux is not None else 0)
@@ -494,9 +504,10 @@ class FFBlockFn(torch.autograd.Function):
         dw2 = linear_bwd_w(dy2, h).to(w2.dtype)
         fuse_db2 = has_ln and add_residual
         db2 = None if fuse_db2 else colsum(dy2).to(w2.dtype)
-        du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u, w_t=weight_t(w2, cdt))
+        du, db1 = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u, w_t=weight_t(w2, cdt),
+                               want_colsum=True)
         dw1 = linear_bwd_w(du, xn).to(w1.dtype)
-        db1 = colsum(du).to(w1.dtype)
+        db1 = db1.to(w1.dtype)
         dxn = linear_bwd_x(du, compute_copy(w1, cdt), w_t=weight_t(w1, cdt))
         dg = db = None
         if has_ln:
