@@ -66,6 +66,29 @@ def cpu_baseline(kw, masked, seconds_budget=20.0):
             "sample": f"oracle fwd+bwd fp32, batch {B}, {steps} timed steps after 1 warm-up"}
 
 
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_traffic.json")
+# timer family -> substring of the kernel's name in the rocprofv3 counter summary
+PMC_KERNEL_OF_FAMILY = {
+    "gemm_nt_phased_kernel|gemm_nt_fast_kernel[plain->bf16]": "gemm_nt_phased_kernelILi0EDF16b",
+    "gemm_tn_phased_kernel|gemm_tn_fast_kernel[+slab_reduce]": "gemm_tn_phased_kernel",
+}
+
+
+def pmc_traffic(family):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC summary of this
+    same workload (counters cannot be read from inside the process): FETCH_SIZE x 2 + WRITE_SIZE."""
+    key = PMC_KERNEL_OF_FAMILY.get(family)
+    if key is None or not os.path.exists(PMC_TRAFFIC_FILE):
+        return {"traffic": None}
+    with open(PMC_TRAFFIC_FILE) as f:
+        kernels = json.load(f)["kernels"]
+    for name, rec in kernels.items():
+        if key in name:
+            return {"traffic": rec["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
+                    "traffic_source": "profiles/r01e_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"}
+    return {"traffic": None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +208,8 @@ def main():
                     "all_gemm_tflops": (sum(f["work"] for f in gemm) / (sum(f["ms"] for f in gemm) * 1e-3) / 1e12)
                     if gemm else None,
                     "time_share_ms_per_step": {f["family"]: round(f["ms"] / args.steps, 3) for f in fams}}
+        if roof is not None and args.workload == "vit_b16_224" and batch == 256:
+            roof.update(pmc_traffic(roof["kernel"]))
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_baseline(kw, masked)
