@@ -119,6 +119,12 @@ long long vitmi_colsum_workspace_bytes(long long rows, int cols);
 int vitmi_colsum(const void* x, int dt, long long rows, int cols, long long ld, float* out, void* workspace,
                  void* stream);
 
+/* The patch gather of Conv2d(k = s = p) + flatten(2).transpose(1, 2) (mymodel/ViT.py:33,43) as a
+ * matrix: out[(b, gy, gx)][(c, i, j)] = x[b, c, gy*p + i, gx*p + j], row-major [B*(H/p)*(W/p)][C*p*p]
+ * in out_dt.  For patch sizes the in-place gather of vitmi_patch_embed_* cannot read in 16-byte
+ * pieces (p % 8 != 0) the host side gathers once and runs the ordinary GEMMs on the result. */
+int vitmi_patchify(const void* x, int x_dt, void* out, int out_dt, int B, int C, int H, int W, int p, void* stream);
+
 /* Patch embedding: Conv2d(C, D, kernel=stride=p) + bias, flatten(2).transpose(1,2)
  * (mymodel/ViT.py:33,43) as an im2col-free GEMM: the A operand is gathered straight from the
  * NCHW image.  x is [B,C,H,W] in x_dt; w is [D, C*p*p] in dt; out token j of image b is

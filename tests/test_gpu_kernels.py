@@ -164,7 +164,8 @@ def test_tokens_gradient_is_deterministic(ops):
 
 # ------------------------------------------------------------------------------------------ patch embedding
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("img,p,C,D,B", [(32, 4, 3, 96, 3), (64, 16, 3, 128, 2), (224, 16, 3, 64, 1), (24, 8, 1, 40, 2)])
+@pytest.mark.parametrize("img,p,C,D,B", [(32, 4, 3, 96, 3), (64, 16, 3, 128, 2), (224, 16, 3, 64, 1), (24, 8, 1, 40, 2),
+                                           (16, 2, 3, 24, 2)])
 def test_patch_embed(ops, dtype, img, p, C, D, B):
     x, w, b = rnd(B, C, img, img, seed=1), rnd(D, C, p, p, seed=2, scale=(C * p * p) ** -0.5), rnd(D, seed=3)
     xr = q(x, dtype).requires_grad_(True)

@@ -36,6 +36,7 @@ SIGNATURES = {
     "vitmi_debug_set_tn_config": (I, [I]),
     "vitmi_colsum_workspace_bytes": (L, [L, I]),
     "vitmi_colsum": (I, [P, I, L, I, L, P, P, P]),
+    "vitmi_patchify": (I, [P, I, P, I, I, I, I, I, I, P]),
     "vitmi_patch_embed_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, L, P]),
     "vitmi_patch_embed_bwd_w_workspace_bytes": (L, [I, I, I, I, I, I, I]),
     "vitmi_patch_embed_bwd_w": (I, [P, I, P, L, P, P, I, I, I, I, I, I, I, P]),

@@ -433,6 +433,24 @@ __global__ void meanpool_bwd_kernel(const T* __restrict__ dout, T* __restrict__ 
     dx[idx] = from_f32<T>(to_f32(dout[(long long)b * D + c]) / (float)N);
 }
 
+// ---------------------------------------------------------------- patch gather (im2col for k = s = p)
+// out[(b, gy, gx)][(c, i, j)] = x[b, c, gy*p + i, gx*p + j]; one thread per output element, writes
+// coalesced, reads in runs of p pixels
+template <typename S, typename T>
+__global__ void patchify_kernel(const S* __restrict__ x, T* __restrict__ out, int C, int H, int W, int p, int gw,
+                                int per, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int E = C * p * p;
+    const long long t = idx / E;
+    const int e = (int)(idx - t * E);
+    const int b = (int)(t / per), tt = (int)(t - (long long)b * per);
+    const int gy = tt / gw, gx = tt - gy * gw;
+    const int c = e / (p * p), q = e - c * p * p;
+    const int i = q / p, j = q - i * p;
+    out[idx] = from_f32<T>(to_f32(x[(((long long)b * C + c) * H + gy * p + i) * W + gx * p + j]));
+}
+
 // ---------------------------------------------------------------- Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, bf16_t* __restrict__ p16, long long n, float lr, float b1, float b2,
@@ -817,5 +835,30 @@ extern "C" int vitmi_adam_step_multi(const vitmi_adam_tensor* tensors, int n_ten
     hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, s, tensors, chunks, chunk_elems, lr / bc1, beta1,
                        beta2, eps, weight_decay, bc2_sqrt, grad_scale);
     VITMI_LAUNCH_CHECK("vitmi_adam_step_multi");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_patchify(const void* x, int x_dt, void* out, int out_dt, int B, int C, int H, int W, int p,
+                              void* stream) {
+    VITMI_CHECK_ARG(x && out, "vitmi_patchify: null pointer");
+    VITMI_CHECK_ARG(B > 0 && C > 0 && p > 0 && H > 0 && W > 0 && H % p == 0 && W % p == 0,
+                    "vitmi_patchify: bad geometry B=%d C=%d H=%d W=%d p=%d", B, C, H, W, p);
+    hipStream_t s = as_stream(stream);
+    const int gw = W / p, per = (H / p) * gw;
+    const long long total = (long long)B * per * C * p * p;
+    ProfScope prof(VITMI_FAM_OTHER, s, (double)total * ((x_dt == VITMI_F32 ? 4 : 2) + (out_dt == VITMI_F32 ? 4 : 2)));
+    dim3 grid(ceil_div(total, 256)), block(256);
+#define PATCHIFY(S, T) \
+    hipLaunchKernelGGL((patchify_kernel<S, T>), grid, block, 0, s, (const S*)x, (T*)out, C, H, W, p, gw, per, total)
+    if (x_dt == VITMI_F32 && out_dt == VITMI_F32) PATCHIFY(float, float);
+    else if (x_dt == VITMI_F32 && out_dt == VITMI_BF16) PATCHIFY(float, bf16_t);
+    else if (x_dt == VITMI_BF16 && out_dt == VITMI_BF16) PATCHIFY(bf16_t, bf16_t);
+    else if (x_dt == VITMI_BF16 && out_dt == VITMI_F32) PATCHIFY(bf16_t, float);
+    else {
+        vitmi_set_error("vitmi_patchify: bad dtype pair %d -> %d", x_dt, out_dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+#undef PATCHIFY
+    VITMI_LAUNCH_CHECK("vitmi_patchify");
     return VITMI_OK;
 }

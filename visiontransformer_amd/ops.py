@@ -247,7 +247,11 @@ def _as2d(x):
 # autograd functions
 # ---------------------------------------------------------------------------------------------
 class PatchEmbedFn(torch.autograd.Function):
-    """Conv2d(k=s=p)+bias then flatten/transpose (mymodel/ViT.py:33,43) -> [B, tokens, D]."""
+    """Conv2d(k=s=p)+bias then flatten/transpose (mymodel/ViT.py:33,43) -> [B, tokens, D].
+
+    Patch sizes that are multiples of 8 are gathered in place by the GEMM's direct-to-LDS loads;
+    others (the 4x4 patches of the CIFAR geometry) are gathered once into a [tokens, C*p*p] matrix
+    that the ordinary GEMMs then read."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, cdt):
@@ -260,34 +264,43 @@ class PatchEmbedFn(torch.autograd.Function):
         if cdt == torch.float32 and x.dtype != torch.float32:
             x = x.float()
         x = x.contiguous()
-        if cdt == torch.bfloat16 and x.dtype != torch.bfloat16 and p % 8 == 0 and W % 8 == 0:
-            # one elementwise pass; the direct-to-LDS patch gather then reads 16-byte bf16 chunks
-            # of the image in place (forward and weight gradient), and the saved copy is half the size
-            ctx.x_dtype = x.dtype
-            x = cast(x, torch.bfloat16)
-        else:
-            ctx.x_dtype = x.dtype
-        w_c = compute_copy(weight, cdt).view(D, C * p * p)
-        out = torch.empty((B, per, D), dtype=cdt, device=x.device)
-        bias_f = bias.detach().float() if bias is not None else None
-        check(lib.vitmi_patch_embed_fwd(_p(x), _dt(x), _p(w_c), _p(bias_f), _p(out), _dt(cdt), B, C, H, W, p, D,
-                                        per * D, _stream()), "vitmi_patch_embed_fwd")
-        ctx.save_for_backward(x, weight)
+        ctx.x_dtype = x.dtype
+        ctx.geom = (B, C, H, W, p, per)
         ctx.cdt = cdt
         ctx.has_bias = bias is not None
-        return out
+        w_c = compute_copy(weight, cdt).view(D, C * p * p)
+        in_place = p % 8 == 0 and W % 8 == 0
+        ctx.in_place = in_place
+        if in_place:
+            if cdt == torch.bfloat16 and x.dtype != torch.bfloat16:
+                # one elementwise pass; the direct-to-LDS patch gather then reads 16-byte bf16 chunks
+                # of the image in place (forward and weight gradient), and the saved copy is half the size
+                x = cast(x, torch.bfloat16)
+            out = torch.empty((B, per, D), dtype=cdt, device=x.device)
+            bias_f = bias.detach().float() if bias is not None else None
+            check(lib.vitmi_patch_embed_fwd(_p(x), _dt(x), _p(w_c), _p(bias_f), _p(out), _dt(cdt), B, C, H, W, p, D,
+                                            per * D, _stream()), "vitmi_patch_embed_fwd")
+            ctx.save_for_backward(x, weight)
+            return out
+        patches = torch.empty((B * per, C * p * p), dtype=cdt, device=x.device)
+        check(lib.vitmi_patchify(_p(x), _dt(x), _p(patches), _dt(cdt), B, C, H, W, p, _stream()), "vitmi_patchify")
+        out, _ = linear_fwd(patches, w_c, bias.detach().float() if bias is not None else None)
+        ctx.save_for_backward(patches, weight)
+        return out.view(B, per, D)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        B, C, H, W = x.shape
-        D, _, p, _ = weight.shape
-        per = (H // p) * (W // p)
+        B, C, H, W, p, per = ctx.geom
+        D = weight.shape[0]
         dy = dy.contiguous()
-        dw = torch.empty((D, C * p * p), dtype=torch.float32, device=x.device)
-        ws = _ws(lib.vitmi_patch_embed_bwd_w_workspace_bytes(_dt(dy), B, C, H, W, p, D), x.device)
-        check(lib.vitmi_patch_embed_bwd_w(_p(x), _dt(x), _p(dy), per * D, _p(dw), _p(ws), _dt(dy), B, C, H, W, p, D,
-                                          _stream()), "vitmi_patch_embed_bwd_w")
+        if ctx.in_place:
+            dw = torch.empty((D, C * p * p), dtype=torch.float32, device=x.device)
+            ws = _ws(lib.vitmi_patch_embed_bwd_w_workspace_bytes(_dt(dy), B, C, H, W, p, D), x.device)
+            check(lib.vitmi_patch_embed_bwd_w(_p(x), _dt(x), _p(dy), per * D, _p(dw), _p(ws), _dt(dy), B, C, H, W, p,
+                                              D, _stream()), "vitmi_patch_embed_bwd_w")
+        else:
+            dw = linear_bwd_w(dy.view(B * per, D), x)                # x holds the gathered patches
         db = colsum(dy.view(B * per, D)) if ctx.has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
