@@ -32,6 +32,9 @@ WORKLOADS = {
                          mlp_dim=3072, dim_head=64), False, 256, 105.378822144),
     "cifar_mask": (dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=12, heads=12,
                         mlp_dim=512), True, 256, 1.327),
+    # the timm-style ViT-S/16 with unk_mask that trainer.py:172-176 builds (dim_head = 384/6 = 64, mlp 1536)
+    "tim_vit_small_mask": (dict(image_size=224, patch_size=16, embed_dim=384, num_classes=100, depth=12, heads=6,
+                                mlp_dim=1536, dim_head=64), "timm", 256, 27.59),
 }
 
 
@@ -123,8 +126,13 @@ def main():
     if args.batch:
         batch = args.batch
     torch.manual_seed(1001)
-    model = (ViT_mask if masked else ViT).VIT(**kw).to(dev)
-    if masked:
+    if masked == "timm":
+        from visiontransformer_amd.vision_transformer import VisionTransformer
+        model = VisionTransformer(img_size=kw["image_size"], patch_size=kw["patch_size"], num_classes=kw["num_classes"],
+                                  embed_dim=kw["embed_dim"], depth=kw["depth"], num_heads=kw["heads"]).to(dev)
+    else:
+        model = (ViT_mask if masked else ViT).VIT(**kw).to(dev)
+    if masked is True:
         model.train_method = "mask"
     model.train()
     reducer = None

@@ -127,3 +127,31 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert rc == -3 and b"256" in _lib.lib.vitmi_last_error()
     with pytest.raises(_lib.VitmiError):
         _lib.check(rc, "attn")
+
+
+def test_timm_style_state_dict_layout_and_rejected_switches():
+    """Key names and shapes of the vendored timm class (tim/models/vision_transformer.py:440-520) and the
+    switches the HIP path does not implement."""
+    from visiontransformer_amd.vision_transformer import VisionTransformer, vit_small_patch16_224
+    m = VisionTransformer(img_size=32, patch_size=4, num_classes=10, embed_dim=48, depth=2, num_heads=3)
+    sd = m.state_dict()
+    expect = {"cls_token": (1, 1, 48), "pos_embed": (1, 66, 48), "patch_embed.proj.weight": (48, 3, 4, 4),
+              "patch_embed.proj.bias": (48,), "norm.weight": (48,), "norm.bias": (48,), "head.weight": (10, 48),
+              "head.bias": (10,)}
+    for i in range(2):
+        b = f"blocks.{i}."
+        expect.update({b + "norm1.weight": (48,), b + "norm1.bias": (48,), b + "attn.qkv.weight": (144, 48),
+                       b + "attn.qkv.bias": (144,), b + "attn.proj.weight": (48, 48), b + "attn.proj.bias": (48,),
+                       b + "norm2.weight": (48,), b + "norm2.bias": (48,), b + "mlp.fc1.weight": (192, 48),
+                       b + "mlp.fc1.bias": (192,), b + "mlp.fc2.weight": (48, 192), b + "mlp.fc2.bias": (48,)})
+    assert {k: tuple(v.shape) for k, v in sd.items()} == expect
+    assert m.unk_embed_index == 65 and m.blocks[0].norm1.eps == 1e-6
+    s = vit_small_patch16_224(num_classes=100)
+    assert s.embed_dim == 384 and len(s.blocks) == 12 and s.blocks[0].attn.num_heads == 6
+    assert tuple(s.pos_embed.shape) == (1, 198, 384)
+    for bad in (dict(qk_norm=True), dict(init_values=1e-5), dict(drop_path_rate=0.1), dict(class_token=False,
+                global_pool="avg"), dict(pre_norm=True)):
+        with pytest.raises(NotImplementedError):
+            VisionTransformer(img_size=32, patch_size=4, embed_dim=48, depth=1, num_heads=3, **bad)
+    with pytest.raises(RuntimeError, match="no CPU fallback|ROCm|device"):
+        m(torch.zeros(1, 3, 32, 32))

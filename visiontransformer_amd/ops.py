@@ -403,15 +403,15 @@ class LinearFn(torch.autograd.Function):
 
 
 class AttnBlockFn(torch.autograd.Function):
-    """[LayerNorm ->] to_qkv -> softmax(q k^T * scale) v -> [to_out] [+ x]
-    (mymodel/ViT.py:58, 93-104, 119) as one autograd node.
+    """[LayerNorm ->] to_qkv (+ optional bias, tim/models/vision_transformer.py:74) ->
+    softmax(q k^T * scale) v -> [to_out] [+ x]  (mymodel/ViT.py:58, 93-104, 119) as one autograd node.
 
     Returns (y, probs); probs is the [B,H,N,N] post-softmax tensor when export is requested
     (the tensor the reference exposes to forward hooks on Attention.attend), else None.
     """
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, eps, add_residual, want_probs, cdt):
+    def forward(ctx, x, ln_w, ln_b, w_qkv, w_out, b_out, heads, eps, add_residual, want_probs, cdt, b_qkv=None):
         _need_gpu(x, w_qkv)
         B, N, D = x.shape
         x2 = _as2d(x)
@@ -426,7 +426,7 @@ class AttnBlockFn(torch.autograd.Function):
             g = mean = rstd = None
             xn = x2
         wq = compute_copy(w_qkv, cdt)
-        qkv, _ = linear_fwd(xn, wq)
+        qkv, _ = linear_fwd(xn, wq, b_qkv.detach().float() if b_qkv is not None else None)
         o, lse, probs = attn_fwd(qkv, B, N, heads, dh, want_probs)
         o2 = o.view(B * N, inner)
         if w_out is not None:
@@ -438,6 +438,7 @@ class AttnBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2, g, mean, rstd, xn if ln_w is not None else None, qkv, o, lse, w_qkv, w_out)
         ctx.meta = (B, N, D, heads, dh, add_residual, cdt, ln_w is not None, b_out is not None,
                     ln_w.dtype if ln_w is not None else None, x.dtype)
+        ctx.bqkv_dtype = b_qkv.dtype if b_qkv is not None else None
         if probs is not None:
             ctx.mark_non_differentiable(probs)
         return y.view(B, N, -1), probs
@@ -466,6 +467,7 @@ class AttnBlockFn(torch.autograd.Function):
         dqkv2 = dqkv.view(B * N, 3 * inner)
         wq = compute_copy(w_qkv, cdt)
         dwq = linear_bwd_w(dqkv2, xn).to(w_qkv.dtype)
+        dbq = colsum(dqkv2).to(ctx.bqkv_dtype) if ctx.bqkv_dtype is not None else None
         dxn = linear_bwd_x(dqkv2, wq, w_t=weight_t(w_qkv, cdt))
         dg = db = None
         if has_ln:
@@ -480,7 +482,7 @@ class AttnBlockFn(torch.autograd.Function):
         dx = dx.view(B, N, D)
         if dx.dtype != in_dtype:
             dx = cast(dx, in_dtype)
-        return dx, dg, db, dwq, dwo, dbo, None, None, None, None, None
+        return dx, dg, db, dwq, dwo, dbo, None, None, None, None, None, dbq
 
 
 class FFBlockFn(torch.autograd.Function):
