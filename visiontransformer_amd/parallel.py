@@ -76,7 +76,9 @@ class GradReducer:
         if p in self._seen:  # second accumulation into the same gradient in one backward
             raise RuntimeError("GradReducer: a parameter received two gradients before finish()")
         self._seen.add(p)
-        b.view(i).copy_(p.grad)
+        dst = b.view(i)
+        if p.grad.data_ptr() != dst.data_ptr():
+            dst.copy_(p.grad)
         b.pending -= 1
         if b.pending == 0:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -96,11 +98,11 @@ class GradReducer:
             b.work.wait()
             if scale != 1.0:
                 b.flat.mul_(scale)
+            # hand out views of the bucket instead of copies: the optimizer reads them before the next
+            # backward refills the bucket (a parameter whose gradient is kept across steps then
+            # accumulates in place inside the bucket, which the refill copies onto itself)
             for i, p in enumerate(b.params):
-                if p.grad is None:
-                    p.grad = b.view(i).clone()
-                else:
-                    p.grad.copy_(b.view(i))
+                p.grad = b.view(i)
             b.pending = len(b.params)
             b.work = None
         self._seen.clear()
