@@ -1,7 +1,9 @@
 """CPU oracle for the ViT encoder hot path (TEST INFRASTRUCTURE, not product code).
 
 A functional, pure-torch fp32/fp64 restatement of the forward pass that the
-reference defines in mymodel/ViT.py and mymodel/ViT_mask.py.  Backward is
+reference defines in mymodel/ViT.py and mymodel/ViT_mask.py, and of the positional-embedding
+variants mymodel/ViT_mask_avg.py (masked tokens take the mean of the unmasked patch rows; 2-D
+table + unk_mask) and mymodel/ViT_ape.py (fixed sinusoidal table; no pos_embedding parameter).  Backward is
 obtained by torch autograd over this forward, exactly as the reference does.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
@@ -74,6 +76,16 @@ def feed_forward(x, w1, b1, w2, b2):
     return gelu_erf(x @ w1.t() + b1) @ w2.t() + b2
 
 
+def sinusoid_table(n, d, max_len=5000):
+    """mymodel/ViT_ape.py:11-32 (PositionalEncoding.pe[0, :n]): sin on even, cos on odd columns."""
+    pe = torch.zeros(max_len, d)
+    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2).float() * (-math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe[:n]
+
+
 def seq_ord_from_mask(unk_mask, unk_embed_index):
     """mymodel/ViT_mask.py:162-163: masked positions re-index to the unknown slot."""
     n = unk_mask.shape[-1]
@@ -114,10 +126,26 @@ def forward_features(params, x, heads, unk_mask=None, train_method="mask", use_p
     tok = patch_embed(x, params["to_patch_embedding.proj.weight"], params["to_patch_embedding.proj.bias"])
     B = tok.shape[0]
     tok = torch.cat([params["cls_token"].expand(B, -1, -1), tok], dim=1)
-    pe = params["pos_embedding"]
-    if pe.dim() == 2:                                   # ViT.py:158-159
+    if "pos_embedding" not in params:                   # ViT_ape.py:162,178-187: fixed sinusoidal table
+        n, d = tok.shape[1], tok.shape[2]
+        pos = sinusoid_table(n, d).unsqueeze(0)
         if unk_mask is not None:
-            raise TypeError("mymodel/ViT.py VIT.forward takes no unk_mask")
+            # the reference reads an undefined attribute here (ViT_ape.py:186); the evident
+            # intent is a zero row for masked positions
+            order = seq_ord_from_mask(unk_mask, n).squeeze(0)
+            pos = torch.cat([pos, torch.zeros(1, 1, d)], dim=1)[:, order, :]
+        pe = None
+    else:
+        pe = params["pos_embedding"]
+    if pe is None:
+        pass
+    elif pe.dim() == 2 and unk_mask is not None:        # ViT_mask_avg.py:165-171
+        n = tok.shape[1]
+        unmask_idx = torch.nonzero((1 - unk_mask).squeeze(0)).squeeze(1).unsqueeze(0)
+        unk_pos = pe[unmask_idx[:, 1:]].mean(1)         # mean over the unmasked PATCH rows (cls excluded)
+        order = seq_ord_from_mask(unk_mask, n)
+        pos = torch.cat([pe, unk_pos], 0)[order]
+    elif pe.dim() == 2:                                 # ViT.py:158-159, ViT_mask_avg.py:173
         pos = pe
     else:                                               # ViT_mask.py:159-170
         n = tok.shape[1]

@@ -11,7 +11,8 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-VIT_CASES = ["cifar_dh8", "dh64_mean", "n197_dh64", "identity_out", "mask_dh8", "mask_none", "mask_dh64"]
+VIT_CASES = ["cifar_dh8", "dh64_mean", "n197_dh64", "identity_out", "mask_dh8", "mask_none", "mask_dh64",
+             "avg_mask", "avg_none", "ape_none"]
 
 
 def pytest_configure(config):
@@ -58,6 +59,8 @@ class Golden:
         self.feat = torch.from_numpy(z["feat"])
         self.unk_mask = torch.from_numpy(z["unk_mask"]) if "unk_mask" in z.files else None
         self.masked = bool(self.cfg.pop("masked"))
+        # reference module the fixture was captured from (older fixtures: ViT or ViT_mask)
+        self.module = self.cfg.pop("module", "ViT_mask" if self.masked else "ViT")
 
     def ctor_kwargs(self):
         return dict(self.cfg)

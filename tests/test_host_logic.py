@@ -17,8 +17,8 @@ from visiontransformer_amd.masking_generator import MaskingGenerator, seq_ord_fr
 
 
 def build_model(g):
-    mod = ViT_mask if g.masked else ViT
-    return mod.VIT(**g.ctor_kwargs())
+    import visiontransformer_amd
+    return getattr(visiontransformer_amd, g.module).VIT(**g.ctor_kwargs())
 
 
 def test_mask_sampler_bit_exact_against_reference_vectors():

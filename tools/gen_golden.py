@@ -41,21 +41,33 @@ CASES = {
                                    heads=12, mlp_dim=128), 4, "nomask"),
     "mask_dh64": ("ViT_mask", dict(image_size=64, patch_size=8, embed_dim=64, num_classes=7, depth=1,
                                    heads=2, mlp_dim=96, dim_head=32), 3, "mask"),
+    # sibling positional-embedding variants (mymodel/ViT_mask_avg.py, mymodel/ViT_ape.py)
+    "avg_mask": ("ViT_mask_avg", dict(image_size=32, patch_size=4, embed_dim=96, num_classes=10, depth=2,
+                                      heads=12, mlp_dim=128), 4, "mask"),
+    "avg_none": ("ViT_mask_avg", dict(image_size=32, patch_size=4, embed_dim=96, num_classes=10, depth=2,
+                                      heads=12, mlp_dim=128), 4, "nomask"),
+    # the masked branch of ViT_ape reads an undefined attribute (ViT_ape.py:186): only unmasked is captured
+    "ape_none": ("ViT_ape", dict(image_size=32, patch_size=4, embed_dim=96, num_classes=10, depth=2,
+                                 heads=12, mlp_dim=128), 4, "nomask"),
 }
 
 
 def main():
     sys.path.insert(0, REF)
     sys.dont_write_bytecode = True
-    from mymodel import ViT, ViT_mask
+    from mymodel import ViT, ViT_ape, ViT_mask, ViT_mask_avg
     from utils.masking_generator import MaskingGenerator
+    modules = {"ViT": ViT, "ViT_mask": ViT_mask, "ViT_mask_avg": ViT_mask_avg, "ViT_ape": ViT_ape}
+    only = set(sys.argv[1:])          # optional: case names to (re)generate; masks.npz only on a full run
 
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)  # deterministic reduction order for the captured numbers
 
     for name, (modname, kw, B, mode) in CASES.items():
+        if only and name not in only:
+            continue
         torch.manual_seed(1001)
-        mod = ViT if modname == "ViT" else ViT_mask
+        mod = modules[modname]
         model = mod.VIT(**kw)
         model.train()
         # make LayerNorm affine / biases non-trivial so their gradients and use are exercised
@@ -75,8 +87,9 @@ def main():
         feats = []
         hooks.append(model.transformer.register_forward_hook(lambda m, i, o: feats.append(o.detach().clone())))
         arrays = {}
-        if modname == "ViT_mask":
-            model.train_method = "mask"
+        if modname != "ViT":
+            if modname == "ViT_mask":
+                model.train_method = "mask"
             if mode == "mask":
                 grid = kw["image_size"] // kw["patch_size"]
                 random.seed(77)
@@ -111,10 +124,13 @@ def main():
             else:
                 arrays["cfg/" + ck] = np.array(cv, dtype=np.int64)
         arrays["cfg/masked"] = np.array(int(modname == "ViT_mask"), dtype=np.int64)
+        arrays["cfg/module"] = np.array(modname)
         path = os.path.join(OUT, f"vit_{name}.npz")
         np.savez_compressed(path, **arrays)
         print(name, "loss", float(loss), "bytes", os.path.getsize(path))
 
+    if only:
+        return
     # ---- mask vectors
     marr = {}
     cases = [(8, 32), (14, 98), (14, 100), (14, 120), (14, 140), (14, 160), (14, 8), (8, 8), (4, 8)]

@@ -212,10 +212,7 @@ class _VITBase(_HipModule):
         if self.masked:
             self.unk_embed_index = num_patches + 1
         self.PE = True          # the reference ignores its PE argument (ViT.py:136); callers set it afterwards
-        if self.masked:
-            self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 2, embed_dim))
-        else:
-            self.pos_embedding = nn.Parameter(torch.randn(num_patches + 1, embed_dim))
+        self._make_pos_embedding(num_patches, embed_dim)
         self.cls_token = nn.Parameter(torch.randn(1, 1, embed_dim))
         self.dropout = nn.Dropout(emb_dropout)
         if self.masked:
@@ -230,6 +227,12 @@ class _VITBase(_HipModule):
         self.mlp_head[1].out_dtype = torch.float32
         self.embed_dim = embed_dim
         self.num_tokens = num_patches + 1
+
+    def _make_pos_embedding(self, num_patches, embed_dim):
+        if self.masked:
+            self.pos_embedding = nn.Parameter(torch.randn(1, num_patches + 2, embed_dim))
+        else:
+            self.pos_embedding = nn.Parameter(torch.randn(num_patches + 1, embed_dim))
 
     # ---- runtime switches ---------------------------------------------------------------
     def set_compute_dtype(self, dtype):
@@ -250,13 +253,15 @@ class _VITBase(_HipModule):
     def _seq_ord(self, n, unk_mask, device):
         return None
 
+    def _pe_table(self, n, unk_mask, device):
+        """(table [rows, D], seq_ord or None): token i receives table[seq_ord[i]] (row i without seq_ord)."""
+        return self.pos_embedding.view(-1, self.pos_embedding.shape[-1]), self._seq_ord(n, unk_mask, device)
+
     def forward_features(self, x, unk_mask=None):
         """Token sequence after the last block, [B, N, D] (timm naming; vit_rollout.py:98)."""
         tok = self.to_patch_embedding(x)
         n = tok.shape[1] + 1
-        use_pe = bool(self.PE)
-        seq_ord = self._seq_ord(n, unk_mask, tok.device) if use_pe else None
-        pe2d = self.pos_embedding.view(-1, self.pos_embedding.shape[-1]) if use_pe else None
+        pe2d, seq_ord = self._pe_table(n, unk_mask, tok.device) if bool(self.PE) else (None, None)
         x = ops.TokensFn.apply(tok, self.cls_token, pe2d, seq_ord)
         x = self.dropout(x)
         return self.transformer(x)
@@ -295,6 +300,66 @@ class VIT_mask(_VITBase):
             ar = torch.arange(n, device=device, dtype=torch.long)
             return (ar * (1 - m) - m).contiguous()
         return None
+
+    def forward(self, x, unk_mask=None):
+        return self._head(self.forward_features(x, unk_mask))
+
+
+def _masked_order(n, unk_mask, unk_index, device):
+    m = unk_mask.to(device=device, dtype=torch.long).reshape(-1)
+    ar = torch.arange(n, device=device, dtype=torch.long)
+    return m, (ar * (1 - m) + m * unk_index).contiguous()
+
+
+class VIT_mask_avg(_VITBase):
+    """mymodel/ViT_mask_avg.py:123-182 (exported as ViT_mask_avg.VIT): a 2-D table [N, D]; with an
+    unk_mask every masked token receives the MEAN of the unmasked patch rows (the class row excluded,
+    :167-168).  The [N+1, D] table with that extra row is assembled by ordinary tensor ops on the
+    device (it is N x D numbers); the gather-add over the batch and its backward are the HIP kernels."""
+    masked = False
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.unk_embed_index = self.num_tokens          # num_patches + 1
+
+    def _pe_table(self, n, unk_mask, device):
+        pe = self.pos_embedding
+        if unk_mask is None:
+            return pe, None
+        m, order = _masked_order(n, unk_mask, self.unk_embed_index, device)
+        keep = (m[1:] == 0).to(pe.dtype)                               # unmasked patch rows
+        unk_pos = (pe[1:] * keep[:, None]).sum(0, keepdim=True) / keep.sum()
+        return torch.cat([pe, unk_pos], 0), order
+
+    def forward(self, x, unk_mask=None):
+        return self._head(self.forward_features(x, unk_mask))
+
+
+class VIT_ape(_VITBase):
+    """mymodel/ViT_ape.py:144-198 (exported as ViT_ape.VIT): the positional table is the fixed
+    sinusoid of :11-32, not a parameter (absent from the state_dict, as in the reference); masked
+    tokens receive no positional row.  The reference's masked branch reads an undefined attribute
+    (:186); its evident intent, a zero row, is what runs here."""
+    masked = False
+
+    def _make_pos_embedding(self, num_patches, embed_dim):
+        import math
+        n = num_patches + 1
+        pe = torch.zeros(n, embed_dim)
+        position = torch.arange(0, n, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, embed_dim, 2).float() * (-math.log(10000.0) / embed_dim))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pos_embedding", pe.unsqueeze(0), persistent=False)
+        self.unk_embed_index = num_patches + 1
+
+    def _pe_table(self, n, unk_mask, device):
+        pe2d = self.pos_embedding.view(-1, self.pos_embedding.shape[-1])
+        if unk_mask is None:
+            return pe2d, None
+        m, _ = _masked_order(n, unk_mask, 0, device)
+        ar = torch.arange(n, device=device, dtype=torch.long)
+        return pe2d, (ar * (1 - m) - m).contiguous()                   # negative index = no positional row
 
     def forward(self, x, unk_mask=None):
         return self._head(self.forward_features(x, unk_mask))
