@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--no-kernel-timers", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("VITMI_BENCH_WATCHDOG"):      # dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VITMI_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,13 +113,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # one rank per GPU; more ranks than GPUs (a rehearsal of the N > 1 path on one card with the gloo
+    # backend, VITMI_DIST_BACKEND=gloo) wraps around
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("VITMI_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from visiontransformer_amd import ViT, ViT_mask, _lib
     from visiontransformer_amd.optim import FusedAdam
