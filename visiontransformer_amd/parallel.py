@@ -15,8 +15,16 @@ import torch.distributed as dist
 def broadcast_parameters(module, src=0, group=None):
     """Rank `src`'s parameters and buffers everywhere (what DDP's constructor does)."""
     with torch.no_grad():
+        by_kind = {}
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=group)
+            by_kind.setdefault((t.dtype, t.device), []).append(t)
+        for tensors in by_kind.values():           # one collective per dtype/device, not one per tensor
+            flat = torch.cat([t.data.reshape(-1) for t in tensors])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in tensors:
+                t.data.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
 
 
 class _Bucket:
