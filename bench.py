@@ -229,7 +229,7 @@ def main():
         if roof is not None and args.workload == "vit_b16_224" and batch == 256:
             roof.update(pmc_traffic(roof["kernel"]))
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # timed on rank 0 of the single-GPU run only
             cpu = cpu_baseline(kw, masked)
         step_tflops = value / world * gflop_img * 1e9 / 1e12
         out = {
