@@ -32,6 +32,10 @@ WORKLOADS = {
                          mlp_dim=3072, dim_head=64), False, 256, 105.378822144),
     "cifar_mask": (dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=12, heads=12,
                         mlp_dim=512), True, 256, 1.327),
+    # the same step with the "pbf" jigsaw augmentation in front (trainer.py:126): masked patches come from a
+    # synthetic public bank [256, 48, 64] (dataloader.py:17-37 shape), images rebuilt by one HIP gather
+    "cifar_mask_pbf": (dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=12, heads=12,
+                            mlp_dim=512), "pbf", 256, 1.327),
     # the timm-style ViT-S/16 with unk_mask that trainer.py:172-176 builds (dim_head = 384/6 = 64, mlp 1536)
     "tim_vit_small_mask": (dict(image_size=224, patch_size=16, embed_dim=384, num_classes=100, depth=12, heads=6,
                                 mlp_dim=1536, dim_head=64), "timm", 256, 27.59),
@@ -128,7 +132,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from visiontransformer_amd import ViT, ViT_mask, _lib
+    from visiontransformer_amd import ViT, ViT_mask, _lib, ops
     from visiontransformer_amd.optim import FusedAdam
     from visiontransformer_amd.parallel import GradReducer, broadcast_parameters
 
@@ -142,7 +146,7 @@ def main():
                                   embed_dim=kw["embed_dim"], depth=kw["depth"], num_heads=kw["heads"]).to(dev)
     else:
         model = (ViT_mask if masked else ViT).VIT(**kw).to(dev)
-    if masked is True:
+    if masked in (True, "pbf"):
         model.train_method = "mask"
     model.train()
     reducer = None
@@ -161,15 +165,25 @@ def main():
         from visiontransformer_amd.masking_generator import MaskingGenerator
         grid = kw["image_size"] // kw["patch_size"]
         gen = MaskingGenerator((grid, grid), grid * grid // 2, min_num_patches=4)
+    jigsaw = None
+    if masked == "pbf":
+        from visiontransformer_amd.masking_generator import JigsawPuzzleMaskedRegion
+        bank = torch.randn(256, 3 * kw["patch_size"] ** 2, grid * grid, generator=torch.Generator().manual_seed(101))
+        jigsaw = JigsawPuzzleMaskedRegion(kw["image_size"], kw["patch_size"], grid * grid // 2, 4, mask_type="pbf",
+                                          device=dev, pub_data=bank)
 
     def step(i):
         nonlocal unk
+        xin = x
         if masked:
             random.seed(1234 + i), np.random.seed(1234 + i)
-            flat, _, _ = gen.masked_indexes()
-            unk = torch.from_numpy(MaskingGenerator.unk_mask_from_flat(flat)).long().to(dev, non_blocking=True)
+            if jigsaw is not None:
+                xin, um = jigsaw(x)
+            else:
+                um = MaskingGenerator.unk_mask_from_flat(gen.masked_indexes()[0])
+            unk = ops.upload(um.astype(np.int64), dev)      # pinned staging: the host does not wait for the stream
         opt.zero_grad(set_to_none=True)
-        logits = model(x, unk_mask=unk) if masked else model(x)
+        logits = model(xin, unk_mask=unk) if masked else model(xin)
         loss = torch.nn.functional.cross_entropy(logits, y)
         loss.backward()
         if reducer is not None:

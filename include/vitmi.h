@@ -125,6 +125,25 @@ int vitmi_colsum(const void* x, int dt, long long rows, int cols, long long ld, 
  * pieces (p % 8 != 0) the host side gathers once and runs the ordinary GEMMs on the result. */
 int vitmi_patchify(const void* x, int x_dt, void* out, int out_dt, int B, int C, int H, int W, int p, void* stream);
 
+/* The image-side half of JigsawPuzzleMaskedRegion.__call__ (masking_generator.py:144-199: Unfold ->
+ * overwrite the masked columns -> Fold) as one patch-level gather that never builds the unfolded
+ * tensor.  x, out: [B,C,H,W] in dt (out must not alias x); src: int32 [L] on the device, L =
+ * (H/p)*(W/p); patch j of out[b] is a copy of
+ *   patch v   of x[b]                  when v = src[j] lies in [0, L)      ("mjp", untouched patches),
+ *   patch v-L of bank[bank_idx[b]]     when v lies in [L, 2L)              ("pbf"; bank: [bank_count,C,H,W]
+ *                                       images in dt, bank_idx: int32 [B] on the device),
+ *   the patch fill[b] ([B,C,p,p], dt)  when v == -2                        ("repeat"),
+ *   zeros                              otherwise                           ("zero").
+ * bank and fill may be null when no src entry selects them. */
+int vitmi_jigsaw_gather(const void* x, void* out, int dt, int B, int C, int H, int W, int p, const int* src,
+                        const void* bank, int bank_count, const int* bank_idx, const void* fill, void* stream);
+
+/* out[b,c,i,j] = (sum_t weight[t] * x[b, c, gy(t)*p+i, gx(t)*p+j]) / L over the L patches t of each image:
+ * to_patches[:, :, seq_ord].mean(2) of the "repeat" branch (masking_generator.py:195-196) with weight[t] =
+ * the number of times patch t occurs in seq_ord.  weight: fp32 [L] on the device; out: [B,C,p,p] in dt. */
+int vitmi_patch_weighted_mean(const void* x, int dt, int B, int C, int H, int W, int p, const float* weight, void* out,
+                              void* stream);
+
 /* Patch embedding: Conv2d(C, D, kernel=stride=p) + bias, flatten(2).transpose(1,2)
  * (mymodel/ViT.py:33,43) as an im2col-free GEMM: the A operand is gathered straight from the
  * NCHW image.  x is [B,C,H,W] in x_dt; w is [D, C*p*p] in dt; out token j of image b is

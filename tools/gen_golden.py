@@ -129,6 +129,8 @@ def main():
         np.savez_compressed(path, **arrays)
         print(name, "loss", float(loss), "bytes", os.path.getsize(path))
 
+    if not only or "jigsaw" in only:
+        gen_jigsaw()
     if only:
         return
     # ---- mask vectors
@@ -159,6 +161,34 @@ def main():
     path = os.path.join(OUT, "masks.npz")
     np.savez_compressed(path, **marr)
     print("masks", idx, "bytes", os.path.getsize(path))
+
+
+def gen_jigsaw():
+    """utils/masking_generator.JigsawPuzzleMaskedRegion('mjp') on seeded images: inputs, RNG seeds and the
+    returned (images, masks) for a few geometries -> tests/golden/jigsaw_mjp.npz."""
+    from utils.masking_generator import JigsawPuzzleMaskedRegion
+    arr = {}
+    cases = [(32, 4, 32, 4, 3, 3), (32, 8, 8, 2, 2, 1), (224, 16, 98, 8, 1, 1), (24, 2, 60, 4, 2, 3)]
+    for i, (img, p, nmask, nmin, B, C) in enumerate(cases):
+        for rep, seed in enumerate((5, 1234)):
+            if img == 224 and rep:                 # one draw of the large geometry keeps the fixture small
+                continue
+            torch.manual_seed(100 + seed)
+            x = torch.randn(B, C, img, img)
+            random.seed(seed)
+            np.random.seed(seed)
+            jig = JigsawPuzzleMaskedRegion(img_size=img, patch_size=p, num_masking_patches=nmask, min_num_patches=nmin,
+                                           mask_type="mjp")
+            out, masks = jig(x.clone())
+            k = f"{i}_{rep}"
+            arr[k + "/meta"] = np.array([img, p, nmask, nmin, B, C, seed], dtype=np.int64)
+            arr[k + "/x"] = x.numpy()
+            arr[k + "/out"] = out.numpy()
+            arr[k + "/masks"] = masks
+    arr["keys"] = np.array(sorted(k[:-5] for k in arr if k.endswith("/meta")))
+    path = os.path.join(OUT, "jigsaw_mjp.npz")
+    np.savez_compressed(path, **arr)
+    print("jigsaw", len(arr["keys"]), "bytes", os.path.getsize(path))
 
 
 if __name__ == "__main__":

@@ -37,6 +37,8 @@ SIGNATURES = {
     "vitmi_colsum_workspace_bytes": (L, [L, I]),
     "vitmi_colsum": (I, [P, I, L, I, L, P, P, P]),
     "vitmi_patchify": (I, [P, I, P, I, I, I, I, I, I, P]),
+    "vitmi_jigsaw_gather": (I, [P, P, I, I, I, I, I, I, P, P, I, P, P, P]),
+    "vitmi_patch_weighted_mean": (I, [P, I, I, I, I, I, I, P, P, P]),
     "vitmi_patch_embed_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, L, P]),
     "vitmi_patch_embed_bwd_w_workspace_bytes": (L, [I, I, I, I, I, I, I]),
     "vitmi_patch_embed_bwd_w": (I, [P, I, P, L, P, P, I, I, I, I, I, I, I, P]),

@@ -451,6 +451,68 @@ __global__ void patchify_kernel(const S* __restrict__ x, T* __restrict__ out, in
     out[idx] = from_f32<T>(to_f32(x[(((long long)b * C + c) * H + gy * p + i) * W + gx * p + j]));
 }
 
+// ---------------------------------------------------------------- patch-level image gather (jigsaw augmentation)
+// out[b] patch j is a whole-patch copy chosen by src[j]: v in [0, L) -> patch v of x[b]; v in [L, 2L) -> patch v-L of
+// bank image bank_idx[b]; -2 -> the per-sample patch fill[b]; anything else -> zeros.  Pure byte movement in units of
+// U bytes (a unit never crosses a patch row), one thread per output unit, reads and writes in runs of one patch row.
+template <typename U>
+__global__ void jigsaw_gather_kernel(const unsigned char* __restrict__ x, unsigned char* __restrict__ out,
+                                     const int* __restrict__ src, const unsigned char* __restrict__ bank, int bank_count,
+                                     const int* __restrict__ bank_idx, const unsigned char* __restrict__ fill, int C, int H,
+                                     int gw, int L, int prow /* bytes of one patch row */, int p, long long row_bytes,
+                                     long long total_units) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_units) return;
+    const int upr = (int)(row_bytes / (int)sizeof(U));          // units per image row
+    const long long r = idx / upr;                                // (b*C + c)*H + y
+    const int xb = (int)(idx - r * upr) * (int)sizeof(U);        // byte offset inside the row
+    const int y = (int)(r % H);
+    const long long bc = r / H;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    const int gx = xb / prow, within = xb - gx * prow;
+    const int gy = y / p, iy = y - gy * p;
+    const int v = src[gy * gw + gx];
+    U val;
+    memset(&val, 0, sizeof(U));
+    const unsigned char* from = nullptr;
+    if (v >= 0 && v < L) {
+        const int sy = v / gw, sx = v - sy * gw;
+        from = x + (((long long)b * C + c) * H + sy * p + iy) * row_bytes + (long long)sx * prow + within;
+    } else if (v >= L && v < 2 * L && bank != nullptr) {
+        const int bi = bank_idx[b];
+        if (bi >= 0 && bi < bank_count) {
+            const int sp = v - L, sy = sp / gw, sx = sp - sy * gw;
+            from = bank + (((long long)bi * C + c) * H + sy * p + iy) * row_bytes + (long long)sx * prow + within;
+        }
+    } else if (v == -2 && fill != nullptr) {
+        from = fill + (((long long)b * C + c) * p + iy) * prow + within;
+    }
+    if (from) val = *reinterpret_cast<const U*>(from);
+    *reinterpret_cast<U*>(out + r * row_bytes + xb) = val;
+}
+
+// out[b, c, i, j] = (sum over patches t of weight[t] * x[b, c, gy(t)*p + i, gx(t)*p + j]) / L
+template <typename T>
+__global__ void patch_weighted_mean_kernel(const T* __restrict__ x, const float* __restrict__ weight, T* __restrict__ out,
+                                           int C, int H, int W, int p, int gw, int L, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int j = (int)(idx % p);
+    const int i = (int)((idx / p) % p);
+    const long long bc = idx / (p * p);
+    const T* img = x + bc * H * W;
+    float acc = 0.f;
+    for (int t = 0; t < L; ++t) {
+        const float w = weight[t];
+        if (w != 0.f) {
+            const int gy = t / gw, gx = t - gy * gw;
+            acc += w * to_f32(img[(long long)(gy * p + i) * W + gx * p + j]);
+        }
+    }
+    out[idx] = from_f32<T>(acc / (float)L);
+}
+
 // ---------------------------------------------------------------- Adam
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, bf16_t* __restrict__ p16, long long n, float lr, float b1, float b2,
@@ -860,5 +922,59 @@ extern "C" int vitmi_patchify(const void* x, int x_dt, void* out, int out_dt, in
     }
 #undef PATCHIFY
     VITMI_LAUNCH_CHECK("vitmi_patchify");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_jigsaw_gather(const void* x, void* out, int dt, int B, int C, int H, int W, int p, const int* src,
+                                   const void* bank, int bank_count, const int* bank_idx, const void* fill, void* stream) {
+    VITMI_CHECK_ARG(x && out && src, "vitmi_jigsaw_gather: null pointer");
+    VITMI_CHECK_ARG(x != out, "vitmi_jigsaw_gather: the gather cannot run in place");
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_jigsaw_gather: bad dtype %d", dt);
+    VITMI_CHECK_ARG(B > 0 && C > 0 && p > 0 && H > 0 && W > 0 && H % p == 0 && W % p == 0,
+                    "vitmi_jigsaw_gather: bad geometry B=%d C=%d H=%d W=%d p=%d", B, C, H, W, p);
+    VITMI_CHECK_ARG(bank == nullptr || (bank_count > 0 && bank_idx != nullptr),
+                    "vitmi_jigsaw_gather: a bank needs bank_count > 0 and bank_idx");
+    hipStream_t s = as_stream(stream);
+    const int es = dt == VITMI_F32 ? 4 : 2;
+    const int gw = W / p, L = (H / p) * gw, prow = p * es;
+    const long long row_bytes = (long long)W * es;
+    const unsigned long long align = (unsigned long long)(uintptr_t)x | (uintptr_t)out | (uintptr_t)bank | (uintptr_t)fill |
+                                     (unsigned long long)prow;
+    int unit = 16;
+    while (unit > es && (align & (unsigned long long)(unit - 1))) unit >>= 1;
+    const long long total = (long long)B * C * H * (row_bytes / unit);
+    ProfScope prof(VITMI_FAM_OTHER, s, 2.0 * B * C * H * (double)row_bytes);
+    dim3 grid(ceil_div(total, 256)), block(256);
+#define JIGSAW(U)                                                                                                      \
+    hipLaunchKernelGGL((jigsaw_gather_kernel<U>), grid, block, 0, s, (const unsigned char*)x, (unsigned char*)out, src,   \
+                       (const unsigned char*)bank, bank_count, bank_idx, (const unsigned char*)fill, C, H, gw, L, prow, p, \
+                       row_bytes, total)
+    if (unit == 16) JIGSAW(uint4);
+    else if (unit == 8) JIGSAW(uint2);
+    else if (unit == 4) JIGSAW(unsigned int);
+    else JIGSAW(unsigned short);
+#undef JIGSAW
+    VITMI_LAUNCH_CHECK("vitmi_jigsaw_gather");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_patch_weighted_mean(const void* x, int dt, int B, int C, int H, int W, int p, const float* weight,
+                                         void* out, void* stream) {
+    VITMI_CHECK_ARG(x && out && weight, "vitmi_patch_weighted_mean: null pointer");
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_patch_weighted_mean: bad dtype %d", dt);
+    VITMI_CHECK_ARG(B > 0 && C > 0 && p > 0 && H > 0 && W > 0 && H % p == 0 && W % p == 0,
+                    "vitmi_patch_weighted_mean: bad geometry B=%d C=%d H=%d W=%d p=%d", B, C, H, W, p);
+    hipStream_t s = as_stream(stream);
+    const int gw = W / p, L = (H / p) * gw;
+    const long long total = (long long)B * C * p * p;
+    ProfScope prof(VITMI_FAM_OTHER, s, (double)B * C * H * W * (dt == VITMI_F32 ? 4 : 2));
+    dim3 grid(ceil_div(total, 256)), block(256);
+    if (dt == VITMI_F32)
+        hipLaunchKernelGGL((patch_weighted_mean_kernel<float>), grid, block, 0, s, (const float*)x, weight, (float*)out, C, H,
+                           W, p, gw, L, total);
+    else
+        hipLaunchKernelGGL((patch_weighted_mean_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, weight, (bf16_t*)out,
+                           C, H, W, p, gw, L, total);
+    VITMI_LAUNCH_CHECK("vitmi_patch_weighted_mean");
     return VITMI_OK;
 }

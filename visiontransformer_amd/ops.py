@@ -42,6 +42,42 @@ def _ws(nbytes, device):
 
 
 # ---------------------------------------------------------------------------------------------
+# small host -> device tables
+# ---------------------------------------------------------------------------------------------
+_UPLOAD_SLOTS = 8
+_upload_ring = {}
+
+
+def upload(arr, device):
+    """A numpy array of 4- or 8-byte items as a device tensor, copied in stream order from a pinned staging slot
+    so the host does not wait for the stream (a copy from pageable memory would).  A slot is reused only after
+    the copy that last read it has finished."""
+    import numpy as np
+    arr = np.ascontiguousarray(arr)
+    tdt = {"int32": torch.int32, "int64": torch.int64, "float32": torch.float32}[arr.dtype.name]
+    device = torch.device(device)
+    ring = _upload_ring.get(device)
+    if ring is None:
+        ring = _upload_ring[device] = {"host": [None] * _UPLOAD_SLOTS, "ev": [None] * _UPLOAD_SLOTS, "i": 0}
+    i = ring["i"]
+    ring["i"] = (i + 1) % _UPLOAD_SLOTS
+    if ring["ev"][i] is not None:
+        ring["ev"][i].synchronize()
+    n = arr.nbytes
+    if ring["host"][i] is None or ring["host"][i].numel() < n:
+        ring["host"][i] = torch.empty(max(n, 1 << 14), dtype=torch.uint8).pin_memory()
+    stage = ring["host"][i][:n]
+    stage.numpy()[:] = arr.reshape(-1).view(np.uint8)
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    with torch.cuda.device(device):
+        out.copy_(stage, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    ring["ev"][i] = ev
+    return out.view(tdt).view(arr.shape)
+
+
+# ---------------------------------------------------------------------------------------------
 # compute-dtype copies of fp32 parameters, refreshed when the parameter's version changes
 # ---------------------------------------------------------------------------------------------
 _cast_cache = {}
@@ -231,6 +267,42 @@ def add(a, b):
     y = torch.empty_like(a)
     check(lib.vitmi_add(_p(a), _p(b), _p(y), _dt(a), a.numel(), _stream()), "vitmi_add")
     return y
+
+
+def jigsaw_gather(x, p, src, bank=None, bank_idx=None, fill=None):
+    """Patch-level gather over an image batch (see vitmi_jigsaw_gather).  x [B,C,H,W]; src int32 [L] on the
+    device; bank [P,C,H,W]; bank_idx int32 [B]; fill [B,C,p,p].  Returns a new [B,C,H,W] tensor."""
+    _need_gpu(x, src, bank, bank_idx, fill)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    if src.dtype != torch.int32 or src.numel() != (H // p) * (W // p):
+        raise ValueError("src must be int32 with one entry per patch")
+    for t in (bank, fill):
+        if t is not None and (t.dtype != x.dtype or not t.is_contiguous()):
+            raise ValueError("bank / fill must be contiguous and of the images' dtype")
+    if bank is not None and (tuple(bank.shape[1:]) != (C, H, W) or bank_idx is None or bank_idx.dtype != torch.int32
+                             or bank_idx.numel() != B):
+        raise ValueError("bank must be [P,C,H,W] with an int32 bank_idx per image")
+    if fill is not None and tuple(fill.shape) != (B, C, p, p):
+        raise ValueError("fill must be [B,C,p,p]")
+    out = torch.empty_like(x)
+    check(lib.vitmi_jigsaw_gather(_p(x), _p(out), _dt(x), B, C, H, W, p, _p(src), _p(bank),
+                                  bank.shape[0] if bank is not None else 0, _p(bank_idx), _p(fill), _stream()),
+          "vitmi_jigsaw_gather")
+    return out
+
+
+def patch_weighted_mean(x, p, weight):
+    """[B,C,p,p]: weighted mean of each image's patches (see vitmi_patch_weighted_mean); weight fp32 [L]."""
+    _need_gpu(x, weight)
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    if weight.dtype != torch.float32 or weight.numel() != (H // p) * (W // p):
+        raise ValueError("weight must be float32 with one entry per patch")
+    out = torch.empty((B, C, p, p), dtype=x.dtype, device=x.device)
+    check(lib.vitmi_patch_weighted_mean(_p(x), _dt(x), B, C, H, W, p, _p(weight), _p(out), _stream()),
+          "vitmi_patch_weighted_mean")
+    return out
 
 
 def _as2d(x):
