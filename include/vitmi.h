@@ -144,6 +144,23 @@ int vitmi_jigsaw_gather(const void* x, void* out, int dt, int B, int C, int H, i
 int vitmi_patch_weighted_mean(const void* x, int dt, int B, int C, int H, int W, int p, const float* weight, void* out,
                               void* stream);
 
+/* Attention rollout (vit_rollout.py:18-61; the variant at trainer.py:17-44) over the L exported probability
+ * tensors of one forward pass.  probs: HOST array of L device pointers, each [B,H,N,N] in dt, in layer order.
+ * Per layer and sample: heads fused (head_fusion 0 mean, 1 max, 2 min), the discard_k smallest entries of the
+ * flattened [N*N] matrix zeroed (topk(..., largest=False) + scatter_; the caller passes
+ * discard_k = int(N*N*discard_ratio); keep_first != 0 leaves flat entry 0 out of the candidates as
+ * trainer.py:32-33 does; among equal values the lowest indices go first, where torch leaves the choice
+ * open), then a = (A + I)/2 with every row divided by its sum.  The result is row 0, columns 1..N-1, of
+ * a_{L-1} ... a_1 a_0, computed as a chain of vector-matrix products; out: fp32 [B, N-1], final_mode 0 = as is
+ * (trainer.py:44), 1 = divided by its maximum and passed through softmax (vit_rollout.py:51-55).
+ * workspace: vitmi_rollout_workspace_bytes(L, B, N) bytes (the L normalised fp32 matrices). */
+long long vitmi_rollout_workspace_bytes(int L, int B, int N);
+int vitmi_rollout(const void* const* probs, int dt, int L, int B, int H, int N, int head_fusion, int discard_k,
+                  int keep_first, int final_mode, float* out, void* workspace, void* stream);
+
+/* out[b][j-1] = heads-fused probs[b, :, 0, j] for j = 1..N-1: last_attn of vit_rollout.py:64-73. fp32 [B, N-1]. */
+int vitmi_rollout_last_attn(const void* probs, int dt, int B, int H, int N, int head_fusion, float* out, void* stream);
+
 /* Patch embedding: Conv2d(C, D, kernel=stride=p) + bias, flatten(2).transpose(1,2)
  * (mymodel/ViT.py:33,43) as an im2col-free GEMM: the A operand is gathered straight from the
  * NCHW image.  x is [B,C,H,W] in x_dt; w is [D, C*p*p] in dt; out token j of image b is

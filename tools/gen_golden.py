@@ -131,6 +131,8 @@ def main():
 
     if not only or "jigsaw" in only:
         gen_jigsaw()
+    if not only or "rollout" in only:
+        gen_rollout()
     if only:
         return
     # ---- mask vectors
@@ -189,6 +191,45 @@ def gen_jigsaw():
     path = os.path.join(OUT, "jigsaw_mjp.npz")
     np.savez_compressed(path, **arr)
     print("jigsaw", len(arr["keys"]), "bytes", os.path.getsize(path))
+
+
+def _reference_functions(path, names):
+    """Compile only the named top-level function definitions of a reference file (its module-level imports --
+    torchvision, cv2 -- are absent in this image, the functions themselves are pure torch)."""
+    import ast
+    tree = ast.parse(open(path).read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in body) == sorted(names), path
+    ns = {"torch": torch}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def gen_rollout():
+    """vit_rollout.rollout / last_attn and trainer.rollout on seeded softmax tensors -> tests/golden/rollout.npz."""
+    ref_rollout, ref_last = _reference_functions(os.path.join(REF, "vit_rollout.py"), ["rollout", "last_attn"])
+    (trainer_rollout,) = _reference_functions(os.path.join(REF, "trainer.py"), ["rollout"])
+    arr = {}
+    keys = []
+    for ci, (B, H, N, L) in enumerate([(2, 3, 17, 3), (2, 3, 65, 3), (1, 3, 197, 2)]):
+        torch.manual_seed(500 + ci)
+        atts = [torch.softmax(2.0 * torch.randn(B, H, N, N), dim=-1) for _ in range(L)]
+        for l, a in enumerate(atts):
+            arr[f"c{ci}/att{l}"] = a.numpy()
+        arr[f"c{ci}/meta"] = np.array([B, H, N, L], dtype=np.int64)
+        for fusion in ("mean", "max", "min"):
+            for ratio in (0.9, 0.5, 0.0):
+                if N == 197 and (fusion != "mean" or ratio != 0.9):
+                    continue
+                k = f"c{ci}/{fusion}/{ratio}"
+                keys.append(k)
+                arr[k + "/roll"] = ref_rollout([a.clone() for a in atts], ratio, fusion, "cpu").numpy()
+                arr[k + "/trainer"] = trainer_rollout([a.clone() for a in atts], ratio, fusion).numpy()
+                arr[k + "/last"] = ref_last([a.clone() for a in atts], fusion).numpy()
+    arr["keys"] = np.array(keys)
+    path = os.path.join(OUT, "rollout.npz")
+    np.savez_compressed(path, **arr)
+    print("rollout", len(keys), "bytes", os.path.getsize(path))
 
 
 if __name__ == "__main__":
