@@ -173,6 +173,12 @@ long long vitmi_patch_embed_bwd_w_workspace_bytes(int dt, int B, int C, int H, i
 int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, long long dy_batch_stride, float* dw,
                             void* workspace, int dt, int B, int C, int H, int W, int p, int D, void* stream);
 
+/* seq_ord[i] = i*(1 - m[i]) + m[i]*masked_row for i < n: the index arithmetic of ViT_mask.py:162-163
+ * (masked_row = unk_embed_index) in one launch; masked_row = -1 marks "no positional row" for the variants
+ * that zero the masked positions (ViT_ape.py:186-190).  unk_mask: n entries of int64 (mask_is_int64 != 0) or
+ * int32 on the device, values 0/1; seq_ord: int64 [n]. */
+int vitmi_seq_ord(const void* unk_mask, int mask_is_int64, long long* seq_ord, int n, long long masked_row, void* stream);
+
 /* Token assembly + positional embedding (mymodel/ViT.py:155-159; ViT_mask.py:156-172):
  *   out[b,0,:]   = cls[:]          + pe[row(0),:]
  *   out[b,1+j,:] = patch[b,j,:]    + pe[row(1+j),:]

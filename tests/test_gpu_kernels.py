@@ -3,6 +3,8 @@ plain fp32 torch expression of the same op) on seeded inputs.  fp32 kernels: 1e-
 bf16 kernels: 2e-2 relative (relative = max|a-b| / max|b|)."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -324,3 +326,22 @@ def test_fused_adam_matches_torch_adam(ops):
         assert rel_err(b, a.detach()) < 1e-6
     assert ops.compute_copy(our_p[-1], torch.bfloat16) is w16
     assert torch.equal(w16.cpu(), our_p[-1].detach().cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("mdt", [torch.int64, torch.int32])
+def test_seq_ord_kernel_bit_exact_against_reference_vectors(mdt):
+    """vitmi_seq_ord against the seq_ord arrays captured from the reference's index arithmetic (masks.npz)."""
+    import os
+    from conftest import GOLDEN
+    from visiontransformer_amd import ops
+    z = np.load(os.path.join(GOLDEN, "masks.npz"), allow_pickle=False)
+    for i in range(int(z["count"])):
+        um = torch.from_numpy(z[f"{i}/unk_mask"]).to(mdt)
+        n = um.shape[1]
+        got = ops.seq_ord(um.to(DEV), n, n, DEV)
+        assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy()[None, :], z[f"{i}/seq_ord"])
+        neg = ops.seq_ord(um, n, -1, DEV).cpu().numpy()                  # host mask, "no row" marker
+        m = z[f"{i}/unk_mask"].reshape(-1).astype(np.int64)
+        assert np.array_equal(neg, np.arange(n) * (1 - m) - m)
+    with pytest.raises(ValueError):
+        ops.seq_ord(torch.zeros(1, 5, dtype=torch.long, device=DEV), 6, 6, DEV)

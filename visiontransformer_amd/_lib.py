@@ -40,6 +40,7 @@ SIGNATURES = {
     "vitmi_rollout_workspace_bytes": (L, [I, I, I]),
     "vitmi_rollout": (I, [P, I, I, I, I, I, I, I, I, I, P, P, P]),
     "vitmi_rollout_last_attn": (I, [P, I, I, I, I, I, P, P]),
+    "vitmi_seq_ord": (I, [P, I, P, I, L, P]),
     "vitmi_jigsaw_gather": (I, [P, P, I, I, I, I, I, I, P, P, I, P, P, P]),
     "vitmi_patch_weighted_mean": (I, [P, I, I, I, I, I, I, P, P, P]),
     "vitmi_patch_embed_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, L, P]),

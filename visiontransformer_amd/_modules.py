@@ -290,15 +290,11 @@ class VIT_mask(_VITBase):
         if unk_mask is None:
             return None
         if self.train_method == 'mask':
-            m = unk_mask.to(device=device, dtype=torch.long).reshape(-1)
-            ar = torch.arange(n, device=device, dtype=torch.long)
-            return (ar * (1 - m) + m * self.unk_embed_index).contiguous()
+            return ops.seq_ord(unk_mask, n, self.unk_embed_index, device)
         if self.train_method == 'zero':
             # the reference's 'zero' branch reads an undefined attribute (ViT_mask.py:169); its
             # evident intent -- masked tokens receive a zero positional row -- is implemented
-            m = unk_mask.to(device=device, dtype=torch.long).reshape(-1)
-            ar = torch.arange(n, device=device, dtype=torch.long)
-            return (ar * (1 - m) - m).contiguous()
+            return ops.seq_ord(unk_mask, n, -1, device)                  # negative index = no positional row
         return None
 
     def forward(self, x, unk_mask=None):
@@ -307,8 +303,7 @@ class VIT_mask(_VITBase):
 
 def _masked_order(n, unk_mask, unk_index, device):
     m = unk_mask.to(device=device, dtype=torch.long).reshape(-1)
-    ar = torch.arange(n, device=device, dtype=torch.long)
-    return m, (ar * (1 - m) + m * unk_index).contiguous()
+    return m, ops.seq_ord(m, n, unk_index, device)
 
 
 class VIT_mask_avg(_VITBase):
@@ -357,9 +352,7 @@ class VIT_ape(_VITBase):
         pe2d = self.pos_embedding.view(-1, self.pos_embedding.shape[-1])
         if unk_mask is None:
             return pe2d, None
-        m, _ = _masked_order(n, unk_mask, 0, device)
-        ar = torch.arange(n, device=device, dtype=torch.long)
-        return pe2d, (ar * (1 - m) - m).contiguous()                   # negative index = no positional row
+        return pe2d, ops.seq_ord(unk_mask, n, -1, device)              # negative index = no positional row
 
     def forward(self, x, unk_mask=None):
         return self._head(self.forward_features(x, unk_mask))

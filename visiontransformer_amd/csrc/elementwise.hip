@@ -451,6 +451,16 @@ __global__ void patchify_kernel(const S* __restrict__ x, T* __restrict__ out, in
     out[idx] = from_f32<T>(to_f32(x[(((long long)b * C + c) * H + gy * p + i) * W + gx * p + j]));
 }
 
+// ---------------------------------------------------------------- positional-row order from the mask
+// seq_ord[i] = i * (1 - m[i]) + m[i] * masked_row  (ViT_mask.py:162-163), int64 out, mask int64 or int32
+template <typename M>
+__global__ void seq_ord_kernel(const M* __restrict__ mask, long long* __restrict__ out, int n, long long masked_row) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long m = (long long)mask[i];
+    out[i] = (long long)i * (1 - m) + m * masked_row;
+}
+
 // ---------------------------------------------------------------- patch-level image gather (jigsaw augmentation)
 // out[b] patch j is a whole-patch copy chosen by src[j]: v in [0, L) -> patch v of x[b]; v in [L, 2L) -> patch v-L of
 // bank image bank_idx[b]; -2 -> the per-sample patch fill[b]; anything else -> zeros.  Pure byte movement in units of
@@ -976,5 +986,20 @@ extern "C" int vitmi_patch_weighted_mean(const void* x, int dt, int B, int C, in
         hipLaunchKernelGGL((patch_weighted_mean_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, weight, (bf16_t*)out,
                            C, H, W, p, gw, L, total);
     VITMI_LAUNCH_CHECK("vitmi_patch_weighted_mean");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_seq_ord(const void* unk_mask, int mask_is_int64, long long* seq_ord, int n, long long masked_row,
+                             void* stream) {
+    VITMI_CHECK_ARG(unk_mask && seq_ord, "vitmi_seq_ord: null pointer");
+    VITMI_CHECK_ARG(n > 0, "vitmi_seq_ord: bad length %d", n);
+    hipStream_t s = as_stream(stream);
+    if (mask_is_int64)
+        hipLaunchKernelGGL((seq_ord_kernel<long long>), dim3(ceil_div(n, 256)), dim3(256), 0, s, (const long long*)unk_mask,
+                           seq_ord, n, masked_row);
+    else
+        hipLaunchKernelGGL((seq_ord_kernel<int>), dim3(ceil_div(n, 256)), dim3(256), 0, s, (const int*)unk_mask, seq_ord, n,
+                           masked_row);
+    VITMI_LAUNCH_CHECK("vitmi_seq_ord");
     return VITMI_OK;
 }

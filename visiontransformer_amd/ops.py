@@ -269,6 +269,20 @@ def add(a, b):
     return y
 
 
+def seq_ord(unk_mask, n, masked_row, device):
+    """int64 [n]: i*(1-m[i]) + m[i]*masked_row from a 0/1 mask of n entries (any integer dtype / device)."""
+    m = unk_mask.reshape(-1)
+    if m.numel() != n:
+        raise ValueError(f"unk_mask has {m.numel()} entries, the sequence has {n} tokens")
+    if m.device != torch.device(device) or m.dtype not in (torch.int64, torch.int32):
+        m = m.to(device=device, dtype=torch.long)
+    m = m.contiguous()
+    _need_gpu(m)
+    out = torch.empty(n, dtype=torch.int64, device=m.device)
+    check(lib.vitmi_seq_ord(_p(m), int(m.dtype == torch.int64), _p(out), n, int(masked_row), _stream()), "vitmi_seq_ord")
+    return out
+
+
 def jigsaw_gather(x, p, src, bank=None, bank_idx=None, fill=None):
     """Patch-level gather over an image batch (see vitmi_jigsaw_gather).  x [B,C,H,W]; src int32 [L] on the
     device; bank [P,C,H,W]; bank_idx int32 [B]; fill [B,C,p,p].  Returns a new [B,C,H,W] tensor."""

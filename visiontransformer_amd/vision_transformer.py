@@ -230,9 +230,7 @@ class VisionTransformer(_HipModule):
         # tim/models/vision_transformer.py:556-564: masked positions read the last table row
         if unk_mask is None:
             return None
-        m = unk_mask.to(device=device, dtype=torch.long).reshape(-1)
-        ar = torch.arange(n, device=device, dtype=torch.long)
-        return (ar * (1 - m) + m * self.unk_embed_index).contiguous()
+        return ops.seq_ord(unk_mask, n, self.unk_embed_index, device)
 
     def _pos_embed(self, tok, unk_mask=None):
         """cls prepend + positional rows (the first N of the table, or gathered through seq_ord)."""
