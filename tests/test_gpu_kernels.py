@@ -345,3 +345,21 @@ def test_seq_ord_kernel_bit_exact_against_reference_vectors(mdt):
         assert np.array_equal(neg, np.arange(n) * (1 - m) - m)
     with pytest.raises(ValueError):
         ops.seq_ord(torch.zeros(1, 5, dtype=torch.long, device=DEV), 6, 6, DEV)
+
+
+def test_upload_ring_reuses_its_slots_safely():
+    """ops.upload: more uploads than staging slots, every array arrives intact (a slot is rewritten only after the
+    copy that read it has finished), for the three item types."""
+    from visiontransformer_amd import ops
+    rng = np.random.default_rng(0)
+    sent, got = [], []
+    for i in range(3 * ops._UPLOAD_SLOTS + 1):
+        dt = (np.int32, np.int64, np.float32)[i % 3]
+        a = (rng.standard_normal((3, 1 + 37 * i)) * 1000).astype(dt)
+        sent.append(a)
+        got.append(ops.upload(a, DEV))
+    torch.cuda.synchronize()
+    for a, g in zip(sent, got):
+        assert tuple(g.shape) == a.shape and np.array_equal(g.cpu().numpy(), a)
+    big = rng.integers(0, 1 << 30, size=200000).astype(np.int64)          # larger than a slot's initial size
+    assert np.array_equal(ops.upload(big, DEV).cpu().numpy(), big)
