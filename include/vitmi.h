@@ -65,6 +65,10 @@ const char* vitmi_last_error(void);
  * (the reference times whole epochs with time.time(), trainer.py:98,159-161). */
 int vitmi_prof_enable(int on);
 int vitmi_prof_reset(void);
+/* Time only one family (-1: all).  Two event records per launch cost a few microseconds of GPU time each: with
+ * every family timed a ViT-B/16 step runs 3 % slower and a 32x32-pixel step 25 % slower, so a benchmark times
+ * everything during warm-up and only the kernel it reports on inside its timed region. */
+int vitmi_prof_select(int family);
 int vitmi_prof_read(int family, double* total_ms, double* total_work, long long* launches);
 const char* vitmi_prof_name(int family);
 
@@ -221,6 +225,35 @@ int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, 
 long long vitmi_attn_bwd_workspace_bytes(int dt, int B, int N, int H, int DH);
 int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const void* dprobs,
                    void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, void* stream);
+
+/* Whole encoder sub-blocks, each ONE call that enqueues the launches of the sub-block in order on the stream:
+ *   ff block    y = x + W2 gelu(W1 LN(x) + b1) + b2       PreNorm(FeedForward) + residual, mymodel/ViT.py:58,65-73,120
+ *   attn block  y = x + Wout attn(Wqkv LN(x) [+ bqkv]) [+ bout]   PreNorm(Attention) + residual, ViT.py:58,93-104,119
+ * and their backward (what autograd derives for those lines).  No arithmetic of their own: every step is one of
+ * the entry points above; they exist so that the host pays one foreign call per sub-block instead of one per
+ * kernel.  All matrices are dense row-major in dt (weights as nn.Linear stores them, [out, in]); gamma, beta,
+ * biases, mean, rstd, lse and every parameter gradient are fp32.  Saved for backward: xn (normalised input),
+ * mean, rstd, and u / h (MLP pre-activation and activation) or qkv / o / lse.  w*_t: optional transposed copies
+ * [in, out] of the weights for the input-gradient products (NULL: read through strides).  b_qkv, b_out, db_qkv,
+ * db_out and probs may be NULL.  workspace: the matching *_workspace_bytes (temporaries + scratch of the steps). */
+int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x, const float* gamma, const float* beta, float eps,
+                       const void* w1, const float* b1, const void* w2, const float* b2, void* xn, float* mean,
+                       float* rstd, void* u, void* h, void* y, void* stream);
+long long vitmi_ff_block_bwd_workspace_bytes(int dt, int rows, int D, int M);
+int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const void* x, const void* xn, const void* u,
+                       const void* h, const float* gamma, const float* mean, const float* rstd, const void* w1,
+                       const void* w1_t, const void* w2, const void* w2_t, void* dx, float* dgamma, float* dbeta,
+                       float* dw1, float* db1, float* dw2, float* db2, void* workspace, void* stream);
+int vitmi_attn_block_fwd(int dt, int B, int N, int D, int H, int DH, const void* x, const float* gamma, const float* beta,
+                         float eps, const void* w_qkv, const float* b_qkv, const void* w_out, const float* b_out,
+                         void* xn, float* mean, float* rstd, void* qkv, void* o, float* lse, void* probs, void* y,
+                         void* stream);
+long long vitmi_attn_block_bwd_workspace_bytes(int dt, int B, int N, int D, int H, int DH);
+int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, const void* dy, const void* x, const void* xn,
+                         const void* qkv, const void* o, const float* lse, const float* gamma, const float* mean,
+                         const float* rstd, const void* w_qkv, const void* w_qkv_t, const void* w_out,
+                         const void* w_out_t, void* dx, float* dgamma, float* dbeta, float* dw_qkv, float* db_qkv,
+                         float* dw_out, float* db_out, void* workspace, void* stream);
 
 /* mean over tokens: out[b,:] = mean_i x[b,i,:]  (pool == 'mean', mymodel/ViT.py:164) and its
  * backward dx[b,i,:] = dout[b,:] / N. */

@@ -23,6 +23,7 @@ SIGNATURES = {
     "vitmi_last_error": (c_char_p, []),
     "vitmi_prof_enable": (I, [I]),
     "vitmi_prof_reset": (I, []),
+    "vitmi_prof_select": (I, [I]),
     "vitmi_prof_read": (I, [I, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(c_longlong)]),
     "vitmi_prof_name": (c_char_p, [I]),
     "vitmi_cast": (I, [P, I, P, I, L, P]),
@@ -40,6 +41,12 @@ SIGNATURES = {
     "vitmi_rollout_workspace_bytes": (L, [I, I, I]),
     "vitmi_rollout": (I, [P, I, I, I, I, I, I, I, I, I, P, P, P]),
     "vitmi_rollout_last_attn": (I, [P, I, I, I, I, I, P, P]),
+    "vitmi_ff_block_fwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P]),
+    "vitmi_ff_block_bwd_workspace_bytes": (L, [I, I, I, I]),
+    "vitmi_ff_block_bwd": (I, [I, I, I, I] + [P] * 21),
+    "vitmi_attn_block_fwd": (I, [I, I, I, I, I, I, P, P, P, F] + [P] * 13),
+    "vitmi_attn_block_bwd_workspace_bytes": (L, [I, I, I, I, I, I]),
+    "vitmi_attn_block_bwd": (I, [I, I, I, I, I, I] + [P] * 22),
     "vitmi_seq_ord": (I, [P, I, P, I, L, P]),
     "vitmi_jigsaw_gather": (I, [P, P, I, I, I, I, I, I, P, P, I, P, P, P]),
     "vitmi_patch_weighted_mean": (I, [P, I, I, I, I, I, I, P, P, P]),

@@ -1,0 +1,132 @@
+// Whole encoder sub-blocks as single C-ABI calls: each function enqueues, in order and on one stream, the
+// launches that make up PreNorm(Attention)+residual or PreNorm(FeedForward)+residual (mymodel/ViT.py:52-58,
+// 62-73, 77-104, 119-120) or their backward.  They add no arithmetic of their own -- every step is one of the
+// entry points declared in vitmi.h -- and exist so that a host written in a slow language pays for one foreign
+// call per sub-block instead of one per kernel (at the 32x32-pixel geometry the step time is host time).
+// Temporaries and the scratch of the steps live in one caller-provided workspace: the steps run one after
+// another on the stream, so they share its scratch part.
+#include "common.h"
+
+namespace {
+
+inline long long align256(long long n) { return (n + 255) & ~255ll; }
+inline long long esize(int dt) { return dt == VITMI_F32 ? 4 : 2; }
+inline long long max2(long long a, long long b) { return a > b ? a : b; }
+
+#define STEP(call)                      \
+    do {                                \
+        const int rc__ = (call);        \
+        if (rc__ != VITMI_OK) return rc__; \
+    } while (0)
+
+// dX = dY W for y = x W^T: through the transposed copy W^T [K,N] when the caller has one, else through strides
+int input_grad(int dt, int T, int K, int N, const void* dy, const void* w, const void* w_t, void* dx, int epilogue,
+               void* aux, float* colsum, void* scratch, void* stream) {
+    const void* b = w_t ? w_t : w;
+    const long long sbn = w_t ? N : 1, sbk = w_t ? 1 : K;
+    if (colsum)
+        return vitmi_gemm_colsum(dt, T, K, N, dy, N, 1, b, sbn, sbk, dx, K, dt, epilogue, nullptr, nullptr, 0, aux,
+                                 aux ? K : 0, colsum, scratch, stream);
+    return vitmi_gemm(dt, T, K, N, dy, N, 1, b, sbn, sbk, dx, K, dt, epilogue, nullptr, nullptr, 0, aux, aux ? K : 0,
+                      stream);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ MLP block
+extern "C" int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x, const float* gamma, const float* beta,
+                                  float eps, const void* w1, const float* b1, const void* w2, const float* b2, void* xn,
+                                  float* mean, float* rstd, void* u, void* h, void* y, void* stream) {
+    VITMI_CHECK_ARG(x && gamma && beta && w1 && b1 && w2 && b2 && xn && mean && rstd && u && h && y,
+                    "vitmi_ff_block_fwd: null pointer");
+    VITMI_CHECK_ARG(rows > 0 && D > 0 && M > 0, "vitmi_ff_block_fwd: bad shape rows=%d D=%d M=%d", rows, D, M);
+    STEP(vitmi_layernorm_fwd(x, D, gamma, beta, xn, mean, rstd, dt, rows, D, eps, stream));
+    STEP(vitmi_gemm(dt, rows, M, D, xn, D, 1, w1, D, 1, h, M, dt, VITMI_EPI_GELU, b1, nullptr, 0, u, M, stream));
+    STEP(vitmi_gemm(dt, rows, D, M, h, M, 1, w2, M, 1, y, D, dt, VITMI_EPI_NONE, b2, x, D, nullptr, 0, stream));
+    return VITMI_OK;
+}
+
+extern "C" long long vitmi_ff_block_bwd_workspace_bytes(int dt, int rows, int D, int M) {
+    if (rows <= 0 || D <= 0 || M <= 0) return 0;
+    long long scratch = vitmi_gemm_wgrad_workspace_bytes(dt, D, M, rows);
+    scratch = max2(scratch, vitmi_gemm_wgrad_workspace_bytes(dt, M, D, rows));
+    scratch = max2(scratch, vitmi_gemm_colsum_workspace_bytes(rows, M));
+    scratch = max2(scratch, vitmi_layernorm_bwd_workspace_bytes(rows, D));
+    return align256((long long)rows * M * esize(dt)) + align256((long long)rows * D * esize(dt)) + align256(scratch);
+}
+
+extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const void* x, const void* xn,
+                                  const void* u, const void* h, const float* gamma, const float* mean, const float* rstd,
+                                  const void* w1, const void* w1_t, const void* w2, const void* w2_t, void* dx,
+                                  float* dgamma, float* dbeta, float* dw1, float* db1, float* dw2, float* db2,
+                                  void* workspace, void* stream) {
+    VITMI_CHECK_ARG(dy && x && xn && u && h && gamma && mean && rstd && w1 && w2 && dx && dgamma && dbeta && dw1 && db1 &&
+                        dw2 && db2 && workspace,
+                    "vitmi_ff_block_bwd: null pointer");
+    VITMI_CHECK_ARG(rows > 0 && D > 0 && M > 0, "vitmi_ff_block_bwd: bad shape rows=%d D=%d M=%d", rows, D, M);
+    char* ws = (char*)workspace;
+    void* du = ws;
+    void* dxn = ws + align256((long long)rows * M * esize(dt));
+    void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
+    STEP(vitmi_gemm_wgrad(dt, D, M, rows, dy, D, h, M, dw2, M, scratch, stream));
+    STEP(input_grad(dt, rows, M, D, dy, w2, w2_t, du, VITMI_EPI_DGELU, const_cast<void*>(u), db1, scratch, stream));
+    STEP(vitmi_gemm_wgrad(dt, M, D, rows, du, M, xn, D, dw1, D, scratch, stream));
+    STEP(input_grad(dt, rows, D, M, du, w1, w1_t, dxn, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
+    STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db2, scratch, dt, rows, D, stream));
+    return VITMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------- attention block
+extern "C" int vitmi_attn_block_fwd(int dt, int B, int N, int D, int H, int DH, const void* x, const float* gamma,
+                                    const float* beta, float eps, const void* w_qkv, const float* b_qkv,
+                                    const void* w_out, const float* b_out, void* xn, float* mean, float* rstd, void* qkv,
+                                    void* o, float* lse, void* probs, void* y, void* stream) {
+    VITMI_CHECK_ARG(x && gamma && beta && w_qkv && w_out && xn && mean && rstd && qkv && o && lse && y,
+                    "vitmi_attn_block_fwd: null pointer");
+    VITMI_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && DH > 0, "vitmi_attn_block_fwd: bad shape");
+    const int rows = B * N, I = H * DH;
+    STEP(vitmi_layernorm_fwd(x, D, gamma, beta, xn, mean, rstd, dt, rows, D, eps, stream));
+    STEP(vitmi_gemm(dt, rows, 3 * I, D, xn, D, 1, w_qkv, D, 1, qkv, 3 * I, dt, VITMI_EPI_NONE, b_qkv, nullptr, 0, nullptr,
+                    0, stream));
+    STEP(vitmi_attn_fwd(qkv, o, lse, probs, dt, B, N, H, DH, stream));
+    STEP(vitmi_gemm(dt, rows, D, I, o, I, 1, w_out, I, 1, y, D, dt, VITMI_EPI_NONE, b_out, x, D, nullptr, 0, stream));
+    return VITMI_OK;
+}
+
+extern "C" long long vitmi_attn_block_bwd_workspace_bytes(int dt, int B, int N, int D, int H, int DH) {
+    if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || DH <= 0) return 0;
+    const int rows = B * N, I = H * DH;
+    long long scratch = vitmi_gemm_wgrad_workspace_bytes(dt, D, I, rows);
+    scratch = max2(scratch, vitmi_gemm_wgrad_workspace_bytes(dt, 3 * I, D, rows));
+    scratch = max2(scratch, vitmi_attn_bwd_workspace_bytes(dt, B, N, H, DH));
+    scratch = max2(scratch, vitmi_colsum_workspace_bytes(rows, 3 * I));
+    scratch = max2(scratch, vitmi_layernorm_bwd_workspace_bytes(rows, D));
+    return align256((long long)rows * I * esize(dt)) + align256((long long)rows * 3 * I * esize(dt)) +
+           align256((long long)rows * D * esize(dt)) + align256(scratch);
+}
+
+extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, const void* dy, const void* x,
+                                    const void* xn, const void* qkv, const void* o, const float* lse, const float* gamma,
+                                    const float* mean, const float* rstd, const void* w_qkv, const void* w_qkv_t,
+                                    const void* w_out, const void* w_out_t, void* dx, float* dgamma, float* dbeta,
+                                    float* dw_qkv, float* db_qkv, float* dw_out, float* db_out, void* workspace,
+                                    void* stream) {
+    VITMI_CHECK_ARG(dy && x && xn && qkv && o && lse && gamma && mean && rstd && w_qkv && w_out && dx && dgamma && dbeta &&
+                        dw_qkv && dw_out && workspace,
+                    "vitmi_attn_block_bwd: null pointer");
+    VITMI_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && DH > 0, "vitmi_attn_block_bwd: bad shape");
+    const int rows = B * N, I = H * DH;
+    char* ws = (char*)workspace;
+    void* dout = ws;
+    void* dqkv = ws + align256((long long)rows * I * esize(dt));
+    void* dxn = (char*)dqkv + align256((long long)rows * 3 * I * esize(dt));
+    void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
+    STEP(vitmi_gemm_wgrad(dt, D, I, rows, dy, D, o, I, dw_out, I, scratch, stream));
+    STEP(input_grad(dt, rows, I, D, dy, w_out, w_out_t, dout, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
+    STEP(vitmi_attn_bwd(qkv, o, dout, lse, nullptr, dqkv, scratch, dt, B, N, H, DH, stream));
+    STEP(vitmi_gemm_wgrad(dt, 3 * I, D, rows, dqkv, 3 * I, xn, D, dw_qkv, D, scratch, stream));
+    if (db_qkv) STEP(vitmi_colsum(dqkv, dt, rows, 3 * I, 3 * I, db_qkv, scratch, stream));
+    STEP(input_grad(dt, rows, D, 3 * I, dqkv, w_qkv, w_qkv_t, dxn, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
+    STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db_out, scratch, dt, rows, D, stream));
+    return VITMI_OK;
+}

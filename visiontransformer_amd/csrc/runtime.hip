@@ -40,6 +40,7 @@ struct Family {
 };
 std::mutex g_mu;
 bool g_on = false;
+int g_only = -1;  // >= 0: only this family is timed
 Family g_fam[VITMI_FAM_COUNT];
 std::vector<hipEvent_t> g_pool;  // recycled events: creating one per launch would cost more than recording it
 
@@ -56,7 +57,7 @@ hipEvent_t take_event() {
 }  // namespace
 
 void vitmi_prof_record_begin(int family, hipStream_t s, double work) {
-    if (!g_on) return;
+    if (!g_on || (g_only >= 0 && family != g_only)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Family& f = g_fam[family];
     hipEvent_t a = take_event();
@@ -67,7 +68,7 @@ void vitmi_prof_record_begin(int family, hipStream_t s, double work) {
 }
 
 void vitmi_prof_record_end(int family, hipStream_t s) {
-    if (!g_on) return;
+    if (!g_on || (g_only >= 0 && family != g_only)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Family& f = g_fam[family];
     if (!f.pending) return;
@@ -81,6 +82,13 @@ void vitmi_prof_record_end(int family, hipStream_t s) {
 extern "C" int vitmi_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_on = on != 0;
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_prof_select(int family) {
+    VITMI_CHECK_ARG(family >= -1 && family < VITMI_FAM_COUNT, "vitmi_prof_select: family %d out of range", family);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_only = family;
     return VITMI_OK;
 }
 

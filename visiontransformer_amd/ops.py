@@ -33,7 +33,15 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+# the raw handle of the current stream of the current device; the private getters skip the Stream object that
+# torch.cuda.current_stream() builds on every call (several microseconds, once per kernel launch)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -319,6 +327,9 @@ def patch_weighted_mean(x, p, weight):
     return out
 
 
+_block_ws_bytes = {}     # workspace sizes of the whole-block calls, by shape
+
+
 def _as2d(x):
     """[..., D] -> [rows, D] view with unit column stride (copies only if the layout forbids a view)."""
     D = x.shape[-1]
@@ -505,22 +516,42 @@ class AttnBlockFn(torch.autograd.Function):
             x2 = cast(x2, cdt)
         inner = w_qkv.shape[0] // 3
         dh = inner // heads
-        if ln_w is not None:
+        whole = ln_w is not None and add_residual and w_out is not None and x2.is_contiguous()
+        if whole:                       # the usual pre-norm residual block: one foreign call for the four launches
             g = ln_w.detach().float()
-            xn, mean, rstd = layernorm_fwd(x2, g, ln_b.detach().float(), eps)
+            rows, dev, f32 = B * N, x2.device, torch.float32
+            xn = torch.empty((rows, D), dtype=cdt, device=dev)
+            mean, rstd = torch.empty(rows, dtype=f32, device=dev), torch.empty(rows, dtype=f32, device=dev)
+            qkv = torch.empty((rows, 3 * inner), dtype=cdt, device=dev)
+            o = torch.empty((B, N, inner), dtype=cdt, device=dev)
+            lse = torch.empty((B, heads, N), dtype=f32, device=dev)
+            probs = torch.empty((B, heads, N, N), dtype=cdt, device=dev) if want_probs else None
+            y = torch.empty((rows, D), dtype=cdt, device=dev)
+            check(lib.vitmi_attn_block_fwd(_dt(cdt), B, N, D, heads, dh, _p(x2), _p(g), _p(ln_b.detach().float()), eps,
+                                           _p(compute_copy(w_qkv, cdt)),
+                                           _p(b_qkv.detach().float()) if b_qkv is not None else None,
+                                           _p(compute_copy(w_out, cdt)),
+                                           _p(b_out.detach().float()) if b_out is not None else None, _p(xn), _p(mean),
+                                           _p(rstd), _p(qkv), _p(o), _p(lse), _p(probs), _p(y), _stream()),
+                  "vitmi_attn_block_fwd")
         else:
-            g = mean = rstd = None
-            xn = x2
-        wq = compute_copy(w_qkv, cdt)
-        qkv, _ = linear_fwd(xn, wq, b_qkv.detach().float() if b_qkv is not None else None)
-        o, lse, probs = attn_fwd(qkv, B, N, heads, dh, want_probs)
-        o2 = o.view(B * N, inner)
-        if w_out is not None:
-            wo = compute_copy(w_out, cdt)
-            y, _ = linear_fwd(o2, wo, b_out.detach().float() if b_out is not None else None,
-                              res=x2 if add_residual else None)
-        else:
-            y = add(o2, x2) if add_residual else o2
+            if ln_w is not None:
+                g = ln_w.detach().float()
+                xn, mean, rstd = layernorm_fwd(x2, g, ln_b.detach().float(), eps)
+            else:
+                g = mean = rstd = None
+                xn = x2
+            wq = compute_copy(w_qkv, cdt)
+            qkv, _ = linear_fwd(xn, wq, b_qkv.detach().float() if b_qkv is not None else None)
+            o, lse, probs = attn_fwd(qkv, B, N, heads, dh, want_probs)
+            o2 = o.view(B * N, inner)
+            if w_out is not None:
+                wo = compute_copy(w_out, cdt)
+                y, _ = linear_fwd(o2, wo, b_out.detach().float() if b_out is not None else None,
+                                  res=x2 if add_residual else None)
+            else:
+                y = add(o2, x2) if add_residual else o2
+        ctx.whole = whole
         ctx.save_for_backward(x2, g, mean, rstd, xn if ln_w is not None else None, qkv, o, lse, w_qkv, w_out)
         ctx.meta = (B, N, D, heads, dh, add_residual, cdt, ln_w is not None, b_out is not None,
                     ln_w.dtype if ln_w is not None else None, x.dtype)
@@ -537,6 +568,30 @@ class AttnBlockFn(torch.autograd.Function):
         dy2 = _as2d(dy.contiguous())
         if dy2.dtype != cdt:
             dy2 = cast(dy2, cdt)
+        if ctx.whole and dy2.is_contiguous():
+            rows, dev, f32 = B * N, x2.device, torch.float32
+            dx = torch.empty((rows, D), dtype=cdt, device=dev)
+            dg, db = torch.empty(D, dtype=f32, device=dev), torch.empty(D, dtype=f32, device=dev)
+            dwq = torch.empty((3 * inner, D), dtype=f32, device=dev)
+            dbq = torch.empty(3 * inner, dtype=f32, device=dev) if ctx.bqkv_dtype is not None else None
+            dwo = torch.empty((D, inner), dtype=f32, device=dev)
+            dbo = torch.empty(D, dtype=f32, device=dev) if has_bo else None
+            key = ("attn", _dt(cdt), B, N, D, heads, dh)
+            nbytes = _block_ws_bytes.get(key)
+            if nbytes is None:
+                nbytes = _block_ws_bytes[key] = int(lib.vitmi_attn_block_bwd_workspace_bytes(_dt(cdt), B, N, D, heads, dh))
+            ws = _ws(nbytes, dev)
+            check(lib.vitmi_attn_block_bwd(_dt(cdt), B, N, D, heads, dh, _p(dy2), _p(x2), _p(xn), _p(qkv), _p(o), _p(lse),
+                                           _p(g), _p(mean), _p(rstd), _p(compute_copy(w_qkv, cdt)),
+                                           _p(weight_t(w_qkv, cdt)), _p(compute_copy(w_out, cdt)),
+                                           _p(weight_t(w_out, cdt)), _p(dx), _p(dg), _p(db), _p(dwq), _p(dbq), _p(dwo),
+                                           _p(dbo), _p(ws), _stream()), "vitmi_attn_block_bwd")
+            dx = dx.view(B, N, D)
+            if dx.dtype != in_dtype:
+                dx = cast(dx, in_dtype)
+            return (dx, dg.to(ln_dtype), db.to(ln_dtype), dwq.to(w_qkv.dtype), dwo.to(w_out.dtype),
+                    dbo.to(w_out.dtype) if dbo is not None else None, None, None, None, None, None,
+                    dbq.to(ctx.bqkv_dtype) if dbq is not None else None)
         if xn is None:
             xn = x2
         o2 = o.view(B * N, inner)
@@ -581,14 +636,32 @@ class FFBlockFn(torch.autograd.Function):
         x2 = _as2d(x)
         if x2.dtype != cdt:
             x2 = cast(x2, cdt)
-        if ln_w is not None:
+        whole = ln_w is not None and add_residual and x2.is_contiguous()
+        if whole:                       # the usual pre-norm residual block: one foreign call for the three launches
             g = ln_w.detach().float()
-            xn, mean, rstd = layernorm_fwd(x2, g, ln_b.detach().float(), eps)
+            rows, D = x2.shape
+            M = w1.shape[0]
+            dev = x2.device
+            xn = torch.empty((rows, D), dtype=cdt, device=dev)
+            mean = torch.empty(rows, dtype=torch.float32, device=dev)
+            rstd = torch.empty(rows, dtype=torch.float32, device=dev)
+            u = torch.empty((rows, M), dtype=cdt, device=dev)
+            h = torch.empty((rows, M), dtype=cdt, device=dev)
+            y = torch.empty((rows, D), dtype=cdt, device=dev)
+            check(lib.vitmi_ff_block_fwd(_dt(cdt), rows, D, M, _p(x2), _p(g), _p(ln_b.detach().float()), eps,
+                                         _p(compute_copy(w1, cdt)), _p(b1.detach().float()),
+                                         _p(compute_copy(w2, cdt)), _p(b2.detach().float()), _p(xn), _p(mean),
+                                         _p(rstd), _p(u), _p(h), _p(y), _stream()), "vitmi_ff_block_fwd")
         else:
-            g = mean = rstd = None
-            xn = x2
-        h, u = linear_fwd(xn, compute_copy(w1, cdt), b1.detach().float(), epi=EPI_GELU, want_aux=True)
-        y, _ = linear_fwd(h, compute_copy(w2, cdt), b2.detach().float(), res=x2 if add_residual else None)
+            if ln_w is not None:
+                g = ln_w.detach().float()
+                xn, mean, rstd = layernorm_fwd(x2, g, ln_b.detach().float(), eps)
+            else:
+                g = mean = rstd = None
+                xn = x2
+            h, u = linear_fwd(xn, compute_copy(w1, cdt), b1.detach().float(), epi=EPI_GELU, want_aux=True)
+            y, _ = linear_fwd(h, compute_copy(w2, cdt), b2.detach().float(), res=x2 if add_residual else None)
+        ctx.whole = whole
         ctx.save_for_backward(x2, g, mean, rstd, xn if ln_w is not None else None, u, h, w1, w2)
         ctx.meta = (shape, add_residual, cdt, ln_w is not None, ln_w.dtype if ln_w is not None else None, x.dtype)
         return y.view(*shape[:-1], w2.shape[0])
@@ -600,6 +673,28 @@ class FFBlockFn(torch.autograd.Function):
         dy2 = _as2d(dy.contiguous())
         if dy2.dtype != cdt:
             dy2 = cast(dy2, cdt)
+        if ctx.whole and dy2.is_contiguous():
+            rows, D = x2.shape
+            M = w1.shape[0]
+            dev, f32 = x2.device, torch.float32
+            dx = torch.empty((rows, D), dtype=cdt, device=dev)
+            dg, db = torch.empty(D, dtype=f32, device=dev), torch.empty(D, dtype=f32, device=dev)
+            dw1, db1 = torch.empty((M, D), dtype=f32, device=dev), torch.empty(M, dtype=f32, device=dev)
+            dw2, db2 = torch.empty((D, M), dtype=f32, device=dev), torch.empty(D, dtype=f32, device=dev)
+            key = ("ff", _dt(cdt), rows, D, M)
+            nbytes = _block_ws_bytes.get(key)
+            if nbytes is None:
+                nbytes = _block_ws_bytes[key] = int(lib.vitmi_ff_block_bwd_workspace_bytes(_dt(cdt), rows, D, M))
+            ws = _ws(nbytes, dev)
+            check(lib.vitmi_ff_block_bwd(_dt(cdt), rows, D, M, _p(dy2), _p(x2), _p(xn), _p(u), _p(h), _p(g), _p(mean),
+                                         _p(rstd), _p(compute_copy(w1, cdt)), _p(weight_t(w1, cdt)),
+                                         _p(compute_copy(w2, cdt)), _p(weight_t(w2, cdt)), _p(dx), _p(dg), _p(db),
+                                         _p(dw1), _p(db1), _p(dw2), _p(db2), _p(ws), _stream()), "vitmi_ff_block_bwd")
+            dx = dx.view(shape)
+            if dx.dtype != in_dtype:
+                dx = cast(dx, in_dtype)
+            return (dx, dg.to(ln_dtype), db.to(ln_dtype), dw1.to(w1.dtype), db1.to(w1.dtype), dw2.to(w2.dtype),
+                    db2.to(w2.dtype), None, None, None)
         if xn is None:
             xn = x2
         dw2 = linear_bwd_w(dy2, h).to(w2.dtype)

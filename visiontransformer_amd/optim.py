@@ -20,6 +20,7 @@ class FusedAdam:
         self.step_count = 0
         self.state = {}
         self._tables = {}   # device -> (pinned host buffers, device buffer, copy-done events, parity)
+        self._layouts = {}  # device -> (ids of the tensors, record constants, chunk table)
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -67,27 +68,45 @@ class FusedAdam:
                 raise RuntimeError("FusedAdam runs on ROCm device tensors only")
             by_device.setdefault(p.device, []).append(p)
         for device, plist in by_device.items():
-            recs, chunks, keep = [], [], []
-            for ti, p in enumerate(plist):
+            keep, g_ptr, p_ptr, p16_ptr = [], [], [], []
+            for p in plist:
                 g = p.grad.contiguous()
                 if g.dtype != torch.float32:
                     g = g.float()
                 keep.append(g)
-                m, v = self._state(p)
+                g_ptr.append(g.data_ptr())
+                p_ptr.append(p.data_ptr())
                 hit = ops._cache_lookup((id(p), torch.bfloat16), p)
-                p16 = hit.data_ptr() if hit is not None else 0
+                p16_ptr.append(hit.data_ptr() if hit is not None else 0)
                 # the transposed copy cannot be refreshed in the same pass: drop it, it is rebuilt on use
                 ops._cast_cache.pop((id(p), torch.bfloat16, "T"), None)
-                n = p.numel()
-                recs.extend((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p16, n))
-                for first in range(0, n, CHUNK):
-                    chunks.extend((ti, first))
-            words = np.asarray(recs + chunks, dtype=np.int64)
+            recs, chunks = self._layout(device, plist)
+            recs[:, 0] = p_ptr
+            recs[:, 1] = g_ptr
+            recs[:, 4] = p16_ptr
+            words = np.concatenate([recs.reshape(-1), chunks])
             with torch.cuda.device(device):
                 dev = self._upload(device, words)
-                stream = torch.cuda.current_stream().cuda_stream
-                check(lib.vitmi_adam_step_multi(dev.data_ptr(), len(plist), dev.data_ptr() + 8 * len(recs),
-                                                len(chunks) // 2, CHUNK, self.lr, self.betas[0], self.betas[1],
-                                                self.eps, self.weight_decay, self.step_count, grad_scale, stream),
-                      "vitmi_adam_step_multi")
+                check(lib.vitmi_adam_step_multi(dev.data_ptr(), len(plist), dev.data_ptr() + 8 * recs.size,
+                                                chunks.size // 2, CHUNK, self.lr, self.betas[0], self.betas[1],
+                                                self.eps, self.weight_decay, self.step_count, grad_scale,
+                                                ops._stream()), "vitmi_adam_step_multi")
             del keep
+
+    def _layout(self, device, plist):
+        """(records [len, 6] with the per-tensor constants filled in, chunk table) for this set of tensors; rebuilt
+        only when the set changes (the state tensors never move, gradients and copies are filled in per step)."""
+        key = tuple(id(p) for p in plist)
+        ent = self._layouts.get(device)
+        if ent is None or ent[0] != key:
+            recs = np.zeros((len(plist), 6), dtype=np.int64)
+            chunks = []
+            for ti, p in enumerate(plist):
+                m, v = self._state(p)
+                n = p.numel()
+                recs[ti, 2], recs[ti, 3], recs[ti, 5] = m.data_ptr(), v.data_ptr(), n
+                firsts = np.arange(0, n, CHUNK, dtype=np.int64)
+                chunks.append(np.stack([np.full_like(firsts, ti), firsts], axis=1).reshape(-1))
+            ent = (key, recs, np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.int64))
+            self._layouts[device] = ent
+        return ent[1], ent[2]
