@@ -84,12 +84,22 @@ class GradReducer:
         if p in self._seen:  # second accumulation into the same gradient in one backward
             raise RuntimeError("GradReducer: a parameter received two gradients before finish()")
         self._seen.add(p)
-        dst = b.view(i)
-        if p.grad.data_ptr() != dst.data_ptr():
-            dst.copy_(p.grad)
         b.pending -= 1
         if b.pending == 0:
+            self._pack(b)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _pack(self, b):
+        """Gradients of a complete bucket into its flat buffer: one multi-tensor copy, not one launch per tensor."""
+        dst, src = [], []
+        for i, p in enumerate(b.params):
+            if p in self._seen:
+                v = b.view(i)
+                if p.grad.data_ptr() != v.data_ptr():
+                    dst.append(v)
+                    src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def finish(self):
         """Wait for the exchange; leave averaged gradients in p.grad.  Parameters that took no
@@ -101,6 +111,7 @@ class GradReducer:
                 for i, p in enumerate(b.params):
                     if p not in self._seen:
                         b.view(i).zero_()
+                self._pack(b)
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         for b in self.buckets:
             b.work.wait()
