@@ -152,7 +152,7 @@ def main():
     reducer = None
     if world > 1:
         broadcast_parameters(model, src=0)
-        reducer = GradReducer(model, bucket_mb=64)
+        reducer = GradReducer(model, bucket_mb=64, average=False)   # the 1/world factor rides on the Adam kernel
     opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=5e-5)
 
     torch.manual_seed(1234 + rank)
@@ -188,7 +188,7 @@ def main():
         loss.backward()
         if reducer is not None:
             reducer.finish()
-        opt.step()
+        opt.step(grad_scale=1.0 / world)
         return loss
 
     def sync():
