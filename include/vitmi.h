@@ -291,6 +291,19 @@ int vitmi_adam_step_multi(const vitmi_adam_tensor* tensors, int n_tensors, const
                           int n_chunks, int chunk_elems, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int step, float grad_scale, void* stream);
 
+/* vitmi_transpose_cast (fp32 source) for many matrices in ONE launch: job j writes dst[c][r] = (bf16) src[r][c]
+ * for its rows x cols matrix.  jobs and tile_start live on the device; tile_start[j] = number of 32 x 32 tiles
+ * of the jobs before j (ceil(rows/32) * ceil(cols/32) each), total_tiles their sum = the grid.  Used after the
+ * optimizer step to refresh every transposed weight copy at once (49 launches per step for ViT-B/16 otherwise). */
+typedef struct {
+    const void* src;
+    void* dst;
+    long long rows;
+    long long cols;
+} vitmi_transpose_job;
+int vitmi_transpose_cast_multi(const vitmi_transpose_job* jobs, const long long* tile_start, int n_jobs,
+                               long long total_tiles, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -363,3 +363,27 @@ def test_upload_ring_reuses_its_slots_safely():
         assert tuple(g.shape) == a.shape and np.array_equal(g.cpu().numpy(), a)
     big = rng.integers(0, 1 << 30, size=200000).astype(np.int64)          # larger than a slot's initial size
     assert np.array_equal(ops.upload(big, DEV).cpu().numpy(), big)
+
+
+def test_fused_adam_refreshes_transposed_copies_in_one_launch():
+    """After FusedAdam.step the cached W^T bf16 copies (rebuilt by vitmi_transpose_cast_multi) and the straight
+    copies match the updated fp32 parameters, for ragged and aligned shapes."""
+    from visiontransformer_amd import ops
+    from visiontransformer_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(r, c, device=DEV)) for r, c in [(96, 64), (33, 70), (256, 257), (5, 3)]]
+    ps.append(torch.nn.Parameter(torch.randn(17, device=DEV)))
+    opt = FusedAdam(ps, lr=1e-2)
+    for step in range(3):
+        straight = [ops.compute_copy(p, torch.bfloat16) for p in ps]
+        transposed = [ops.compute_copy_t(p, torch.bfloat16) for p in ps[:4]]
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        before = [p.detach().clone() for p in ps]
+        opt.step()
+        for p, b, s in zip(ps, before, straight):
+            assert not torch.equal(p, b)
+            assert ops.compute_copy(p, torch.bfloat16) is s and torch.equal(s, p.detach().to(torch.bfloat16))
+        for p, t in zip(ps[:4], transposed):
+            assert ops.compute_copy_t(p, torch.bfloat16) is t                     # refreshed in place, not rebuilt
+            assert torch.equal(t, p.detach().t().contiguous().to(torch.bfloat16))

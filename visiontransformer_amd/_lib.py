@@ -47,6 +47,7 @@ SIGNATURES = {
     "vitmi_attn_block_fwd": (I, [I, I, I, I, I, I, P, P, P, F] + [P] * 13),
     "vitmi_attn_block_bwd_workspace_bytes": (L, [I, I, I, I, I, I]),
     "vitmi_attn_block_bwd": (I, [I, I, I, I, I, I] + [P] * 22),
+    "vitmi_transpose_cast_multi": (I, [P, P, I, L, P]),
     "vitmi_seq_ord": (I, [P, I, P, I, L, P]),
     "vitmi_jigsaw_gather": (I, [P, P, I, I, I, I, I, I, P, P, I, P, P, P]),
     "vitmi_patch_weighted_mean": (I, [P, I, I, I, I, I, I, P, P, P]),

@@ -451,6 +451,38 @@ __global__ void patchify_kernel(const S* __restrict__ x, T* __restrict__ out, in
     out[idx] = from_f32<T>(to_f32(x[(((long long)b * C + c) * H + gy * p + i) * W + gx * p + j]));
 }
 
+// ---------------------------------------------------------------- transposed bf16 copies of many fp32 matrices
+// dst[c][r] = (bf16) src[r][c] for every job in one launch: block t finds its job by bisection over the
+// prefix of 32x32-tile counts, then moves one tile through LDS (reads and writes both in runs along a row).
+__global__ __launch_bounds__(256) void transpose_cast_multi_kernel(const vitmi_transpose_job* __restrict__ jobs,
+                                                                  const long long* __restrict__ tile_start, int n_jobs) {
+    __shared__ float tile[32][33];
+    const long long t = blockIdx.x;
+    int lo = 0, hi = n_jobs - 1;
+    while (lo < hi) {                   // last job whose first tile is <= t
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_start[mid] <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    const vitmi_transpose_job job = jobs[lo];
+    const float* in = reinterpret_cast<const float*>(job.src);
+    bf16_t* out = reinterpret_cast<bf16_t*>(job.dst);
+    const int R = (int)job.rows, Cn = (int)job.cols;
+    const int tiles_c = (Cn + 31) >> 5;
+    const int local = (int)(t - tile_start[lo]);
+    const int c0 = (local % tiles_c) * 32, r0 = (local / tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < R && c < Cn) ? in[(long long)r * Cn + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < Cn && r < R) out[(long long)c * R + r] = (bf16_t)tile[tx][k];
+    }
+}
+
 // ---------------------------------------------------------------- positional-row order from the mask
 // seq_ord[i] = i * (1 - m[i]) + m[i] * masked_row  (ViT_mask.py:162-163), int64 out, mask int64 or int32
 template <typename M>
@@ -1001,5 +1033,16 @@ extern "C" int vitmi_seq_ord(const void* unk_mask, int mask_is_int64, long long*
         hipLaunchKernelGGL((seq_ord_kernel<int>), dim3(ceil_div(n, 256)), dim3(256), 0, s, (const int*)unk_mask, seq_ord, n,
                            masked_row);
     VITMI_LAUNCH_CHECK("vitmi_seq_ord");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_transpose_cast_multi(const vitmi_transpose_job* jobs, const long long* tile_start, int n_jobs,
+                                          long long total_tiles, void* stream) {
+    if (n_jobs == 0) return VITMI_OK;
+    VITMI_CHECK_ARG(jobs && tile_start && n_jobs > 0 && total_tiles > 0 && total_tiles < (1ll << 31),
+                    "vitmi_transpose_cast_multi: bad table");
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(transpose_cast_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, jobs, tile_start, n_jobs);
+    VITMI_LAUNCH_CHECK("vitmi_transpose_cast_multi");
     return VITMI_OK;
 }

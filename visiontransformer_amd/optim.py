@@ -68,7 +68,7 @@ class FusedAdam:
                 raise RuntimeError("FusedAdam runs on ROCm device tensors only")
             by_device.setdefault(p.device, []).append(p)
         for device, plist in by_device.items():
-            keep, g_ptr, p_ptr, p16_ptr = [], [], [], []
+            keep, g_ptr, p_ptr, p16_ptr, jobs = [], [], [], [], []
             for p in plist:
                 g = p.grad.contiguous()
                 if g.dtype != torch.float32:
@@ -78,8 +78,12 @@ class FusedAdam:
                 p_ptr.append(p.data_ptr())
                 hit = ops._cache_lookup((id(p), torch.bfloat16), p)
                 p16_ptr.append(hit.data_ptr() if hit is not None else 0)
-                # the transposed copy cannot be refreshed in the same pass: drop it, it is rebuilt on use
-                ops._cast_cache.pop((id(p), torch.bfloat16, "T"), None)
+                # the transposed copy cannot be refreshed in the same pass: all of them go in one launch below
+                hit_t = ops._cache_lookup((id(p), torch.bfloat16, "T"), p)
+                if hit_t is not None and p.dim() == 2 and p.dtype == torch.float32 and p.is_contiguous():
+                    jobs.append((p.data_ptr(), hit_t.data_ptr(), p.shape[0], p.shape[1]))
+                else:
+                    ops._cast_cache.pop((id(p), torch.bfloat16, "T"), None)
             recs, chunks = self._layout(device, plist)
             recs[:, 0] = p_ptr
             recs[:, 1] = g_ptr
@@ -91,6 +95,12 @@ class FusedAdam:
                                                 chunks.size // 2, CHUNK, self.lr, self.betas[0], self.betas[1],
                                                 self.eps, self.weight_decay, self.step_count, grad_scale,
                                                 ops._stream()), "vitmi_adam_step_multi")
+                if jobs:
+                    tiles = [((r + 31) // 32) * ((c + 31) // 32) for _, _, r, c in jobs]
+                    starts = np.concatenate([[0], np.cumsum(tiles)[:-1]]).astype(np.int64)
+                    table = ops.upload(np.concatenate([np.asarray(jobs, dtype=np.int64).reshape(-1), starts]), device)
+                    check(lib.vitmi_transpose_cast_multi(table.data_ptr(), table.data_ptr() + 32 * len(jobs), len(jobs),
+                                                         int(sum(tiles)), ops._stream()), "vitmi_transpose_cast_multi")
             del keep
 
     def _layout(self, device, plist):
