@@ -176,3 +176,33 @@ def test_ape_masked_tokens_get_no_positional_row():
     ref = vit_oracle.forward(g.params, g.x, g.cfg["heads"], unk_mask=unk)
     assert rel_err(logits, ref) < 1e-4
     assert rel_err(logits, g.logits) > 1e-3                        # and it differs from the unmasked result
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", ["yaml_224_dh8", "gray_mean", "ragged_batch"])
+def test_shipped_config_geometries_against_oracle(geom, dtype):
+    """Geometries the reference's own entry points produce that the fixtures do not hold: creat_VIT on
+    config/cifar10 as shipped (224 px, patch 16, D384, 12 heads of 8, mlp 512: N = 197 with 8-wide heads), a
+    one-channel mean-pooled model, and a batch that leaves ragged GEMM tiles."""
+    from visiontransformer_amd import ViT
+    kw, pool, B = {
+        "yaml_224_dh8": (dict(image_size=224, patch_size=16, embed_dim=384, num_classes=10, depth=2, heads=12,
+                              mlp_dim=512), "cls", 3),
+        "gray_mean": (dict(image_size=28, patch_size=7, embed_dim=40, num_classes=10, depth=2, heads=5, mlp_dim=72,
+                           channels=1, dim_head=16), "mean", 9),
+        "ragged_batch": (dict(image_size=32, patch_size=4, embed_dim=192, num_classes=100, depth=2, heads=12,
+                              mlp_dim=512), "cls", 37),
+    }[geom]
+    params = vit_oracle.init_params(seed=11, **kw)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(B, kw.get("channels", 3), kw["image_size"], kw["image_size"], generator=gen)
+    y = torch.randint(0, kw["num_classes"], (B,), generator=gen)
+    logits_ref, loss_ref, grads_ref = vit_oracle.loss_and_grads(params, x, y, kw["heads"], pool=pool)
+    m = ViT.VIT(pool=pool, **kw)
+    m.load_state_dict(params)
+    m = m.to(DEV).set_compute_dtype(dtype)
+    logits = m(x.to(DEV))
+    assert rel_err(logits, logits_ref) < TOL[dtype]
+    torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
+    worst = max((rel_err(p.grad, grads_ref[k]), k) for k, p in m.named_parameters())
+    assert worst[0] < TOL[dtype], worst
