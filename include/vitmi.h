@@ -255,6 +255,27 @@ int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, const void*
                          const void* w_out_t, void* dx, float* dgamma, float* dbeta, float* dw_qkv, float* db_qkv,
                          float* dw_out, float* db_out, void* workspace, void* stream);
 
+/* Per-sample gradient norms for DP-SGD (defence_method/DPSGD.py:114-136, which clips each sample's gradient and
+ * gets per-sample gradients by running the batch one image at a time).  Rows of the [tokens, features]
+ * matrices are cut into segments of `seg` consecutive rows (one image each); every routine ADDS its parameter's
+ * share of ||g_i||^2 to sqnorm[i] (fp32, one entry per segment, zeroed by the caller) without materialising g_i:
+ *   vitmi_wgrad_sqnorm          || U_i^T V_i ||_F^2, the weight of y = x W^T with U = dy [T,P], V = x [T,Q]
+ *                               (bf16 aligned shapes: the weight-gradient MFMA kernel with its token slabs cut at
+ *                               image boundaries, each block reducing its tile to a sum of squares; otherwise one
+ *                               vitmi_gemm_wgrad per image); workspace: vitmi_wgrad_sqnorm_workspace_bytes
+ *   vitmi_seg_colsum_sqnorm     || sum_t x[t,:] ||^2            (biases: x = dy)
+ *   vitmi_seg_layernorm_sqnorm  || sum_t dy*xhat ||^2 + || sum_t dy ||^2   (LayerNorm weight and bias; dy dense [rows,D])
+ *   vitmi_seg_sqnorm            sum_t || x[t,:] ||^2            (positional table, class token: x = dx)
+ * Reductions run in a fixed order; each sqnorm entry has a single writer per launch. */
+long long vitmi_wgrad_sqnorm_workspace_bytes(int dt, int P, int Q, int T, int seg);
+int vitmi_wgrad_sqnorm(int dt, int P, int Q, int T, int seg, const void* U, long long ldu, const void* V, long long ldv,
+                       float* sqnorm, void* workspace, void* stream);
+int vitmi_seg_colsum_sqnorm(const void* x, int dt, long long rows, int cols, long long ld, int seg, float* sqnorm,
+                            void* stream);
+int vitmi_seg_layernorm_sqnorm(const void* dy, const void* x, long long ldx, const float* mean, const float* rstd, int dt,
+                               long long rows, int D, int seg, float* sqnorm, void* stream);
+int vitmi_seg_sqnorm(const void* x, int dt, long long rows, int cols, long long ld, int seg, float* sqnorm, void* stream);
+
 /* mean over tokens: out[b,:] = mean_i x[b,i,:]  (pool == 'mean', mymodel/ViT.py:164) and its
  * backward dx[b,i,:] = dout[b,:] / N. */
 int vitmi_meanpool_fwd(const void* x, void* out, int dt, int B, int N, int D, void* stream);

@@ -1,0 +1,104 @@
+"""Batched DP-SGD (visiontransformer_amd.dpsgd) against per-sample gradients of the CPU oracle run one image at a
+time, the schedule of defence_method/DPSGD.py:115-123.  Bars: per-sample norms and the clipped gradient sum within
+1e-4 (fp32) / 2e-2 (bf16) relative (max|a-b| / max|b|)."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import timm_vit_oracle, vit_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
+CLIP = 0.5
+
+GEOMETRIES = {
+    # cifar geometry (unaligned inner width 96: generic weight-gradient path per image)
+    "cifar": dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=2, heads=12, mlp_dim=512),
+    # 197 tokens per image, aligned widths: the segment mode of the direct-to-LDS weight-gradient kernel,
+    # 128- and 256-wide tiles, segments that are not multiples of the 64-token K-tile
+    "n197": dict(image_size=224, patch_size=16, embed_dim=512, num_classes=10, depth=1, heads=8, mlp_dim=1024,
+                 dim_head=64),
+    "mean_pool": dict(image_size=32, patch_size=8, embed_dim=128, num_classes=7, depth=1, heads=2, mlp_dim=256,
+                      dim_head=64, pool="mean"),
+}
+
+
+def oracle_per_sample(loss_and_grads, params, x, y, heads, **kw):
+    norms, total = [], None
+    for i in range(x.shape[0]):
+        _, _, g = loss_and_grads(params, x[i:i + 1], y[i:i + 1], heads, **kw)
+        n = torch.sqrt(sum((v.double() ** 2).sum() for v in g.values())).float()
+        c = torch.clamp(CLIP / (n + 1e-6), max=1.0)
+        total = {k: v * c for k, v in g.items()} if total is None else {k: total[k] + v * c for k, v in g.items()}
+        norms.append(n)
+    return torch.stack(norms), {k: v / x.shape[0] for k, v in total.items()}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", list(GEOMETRIES))
+def test_norms_and_clipped_sum_against_oracle(geom, dtype):
+    from visiontransformer_amd import ViT, dpsgd
+    kw = GEOMETRIES[geom]
+    B = 5
+    okw = {k: v for k, v in kw.items() if k != "pool"}
+    params = vit_oracle.init_params(masked=False, seed=3, **okw)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 3, kw["image_size"], kw["image_size"], generator=gen)
+    y = torch.randint(0, kw["num_classes"], (B,), generator=gen)
+    pool = kw.get("pool", "cls")
+    ref_norms, ref_grads = oracle_per_sample(vit_oracle.loss_and_grads, params, x, y, kw["heads"], pool=pool)
+    assert (ref_norms > CLIP).any()                       # the clip is active on some sample
+    m = ViT.VIT(**kw)
+    m.load_state_dict(params)
+    m = m.to(DEV).set_compute_dtype(dtype).train()
+    loss, norms = dpsgd.clipped_noised_gradients(m, x.to(DEV), y.to(DEV), l2_norm_clip=CLIP, noise_multiplier=0.0)
+    assert rel_err(norms, ref_norms) < TOL[dtype]
+    worst = max((rel_err(p.grad, ref_grads[k]), k) for k, p in m.named_parameters())
+    assert worst[0] < 2 * TOL[dtype], worst
+    # the literal schedule (B passes of one image) gives the same gradient
+    m2 = ViT.VIT(**kw)
+    m2.load_state_dict(params)
+    m2 = m2.to(DEV).set_compute_dtype(dtype).train()
+    norms2 = dpsgd.literal_step_gradients(m2, x.to(DEV), y.to(DEV), l2_norm_clip=CLIP, noise_multiplier=0.0)
+    assert rel_err(norms2, ref_norms) < TOL[dtype]
+    worst = max((rel_err(p.grad, ref_grads[k]), k) for k, p in m2.named_parameters())
+    assert worst[0] < 2 * TOL[dtype], worst
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_timm_style_model_norms(dtype):
+    """The model DPSGD.py:151 builds (qkv bias, final norm) at a small geometry."""
+    from test_gpu_timm_vit import make
+    from visiontransformer_amd import dpsgd
+    m, params, args = make(dtype)
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 3, 32, 32, generator=gen)
+    y = torch.randint(0, 10, (4,), generator=gen)
+    ref_norms, ref_grads = oracle_per_sample(timm_vit_oracle.loss_and_grads, params, x, y, args["num_heads"])
+    m.train()
+    _, norms = dpsgd.clipped_noised_gradients(m, x.to(DEV), y.to(DEV), l2_norm_clip=CLIP, noise_multiplier=0.0,
+                                              unk_mask=None)
+    assert rel_err(norms, ref_norms) < TOL[dtype]
+    worst = max((rel_err(p.grad, ref_grads[k]), k) for k, p in m.named_parameters())
+    assert worst[0] < 5 * TOL[dtype], worst
+
+
+def test_noise_statistics_and_reproducibility():
+    from visiontransformer_amd import ViT, dpsgd
+    kw = GEOMETRIES["cifar"]
+    torch.manual_seed(2)
+    m = ViT.VIT(**kw).to(DEV).train()
+    x = torch.randn(8, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (8,), device=DEV)
+    dpsgd.clipped_noised_gradients(m, x, y, 1.0, 0.0)
+    clean = {k: p.grad.clone() for k, p in m.named_parameters()}
+    out = []
+    for _ in range(2):
+        gen = torch.Generator(device=DEV).manual_seed(77)
+        dpsgd.clipped_noised_gradients(m, x, y, 1.0, 2.0, generator=gen)
+        out.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    assert all(torch.equal(out[0][k], out[1][k]) for k in clean)            # same generator state, same gradient
+    k = "transformer.layers.0.1.fn.net.0.weight"
+    noise = (out[0][k] - clean[k]) * 8                                          # N(0, (2.0 * 1.0)^2)
+    assert abs(noise.std().item() - 2.0) < 0.05 and abs(noise.mean().item()) < 0.05

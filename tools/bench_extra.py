@@ -66,7 +66,7 @@ def export_points():
                       "images_per_s": 256 / dt, "ms": dt * 1e3, "export_bytes_per_image": nbytes / 256}))
 
 
-def dpsgd_point(small):
+def dpsgd_point(small, batched_only=False):
     torch.manual_seed(1001)
     kw = (dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=12, heads=12, mlp_dim=512) if small else
           dict(image_size=224, patch_size=16, embed_dim=768, num_classes=100, depth=12, heads=12, mlp_dim=3072,
@@ -93,6 +93,18 @@ def dpsgd_point(small):
             p.grad = (a + sigma * clip * torch.randn(a.shape, device=DEV, generator=gen)) / B
         opt.step()
 
+    from visiontransformer_amd import dpsgd
+
+    def batched():
+        dpsgd.clipped_noised_gradients(m, x, y, clip, sigma, generator=gen)
+        opt.step()
+
+    dt = timed(batched, 2, 5)
+    print(json.dumps({"point": f"DP-SGD batched (one forward, norm backward, clipped backward), "
+                               f"{'cifar' if small else 'ViT-B/16'} geometry", "images_per_s": B / dt, "ms": dt * 1e3}),
+          flush=True)
+    if batched_only:
+        return
     dt = timed(step, 1, 2)
     print(json.dumps({"point": f"DP-SGD literal schedule, 256 x (B=1), {'cifar' if small else 'ViT-B/16'} geometry",
                       "images_per_s": B / dt, "ms": dt * 1e3}))
@@ -102,8 +114,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["export", "dpsgd", "all"])
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--batched-only", action="store_true")
     a = ap.parse_args()
     if a.what in ("export", "all"):
         export_points()
     if a.what in ("dpsgd", "all"):
-        dpsgd_point(a.small)
+        dpsgd_point(a.small, a.batched_only)

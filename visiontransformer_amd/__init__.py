@@ -10,7 +10,7 @@ Importing the package loads libvitmi_hip.so; without it the import fails (there 
 fallback compute path).
 """
 from . import _lib  # noqa: F401  (fails loudly when the HIP library is absent)
-from . import ViT, ViT_ape, ViT_mask, ViT_mask_avg, ops  # noqa: F401
+from . import ViT, ViT_ape, ViT_mask, ViT_mask_avg, dpsgd, ops  # noqa: F401
 from .masking_generator import MaskingGenerator  # noqa: F401
 
 __version__ = "0.1.0"

@@ -612,7 +612,10 @@ __device__ __forceinline__ bf16x8 frag_tn(const bf16_t* lds, int col0, int ks, i
 
 // BP x BQ output tile, WP x WQ waves, each wave (BP/WP) x (BQ/WQ); dynamic LDS = two stages of
 // [64 t][BP + BQ] bf16
-template <bool PATCH, int BP, int BQ, int WP, int WQ>
+// SEG: the token axis is cut into segments of `kt_per_slab` TOKENS (one image each) instead of slabs of K-tiles,
+// and the block writes the sum of squares of its tile of the segment's product to C[segment * tiles + tile]
+// rather than the tile itself (per-sample weight-gradient norms).
+template <bool PATCH, int BP, int BQ, int WP, int WQ, bool SEG = false>
 __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t* __restrict__ U, long long ldu,
                                                                     const bf16_t* __restrict__ V, long long ldv,
                                                                     float* __restrict__ C, long long ldc,
@@ -634,8 +637,11 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
     const int wp = wave / WQ, wq = wave % WQ;
     const int fr = lane & 15, fg = lane >> 4;
     const int nk_all = (T + TK - 1) / TK;
-    const int kt_begin = slab * kt_per_slab;
-    const int kt_end = min(kt_begin + kt_per_slab, nk_all);
+    // tokens [t_base + kt*TK, ...) for kt in [kt_begin, kt_end), none at or beyond t_lim
+    const int t_base = SEG ? slab * kt_per_slab : 0;
+    const int t_lim = SEG ? min(T, t_base + kt_per_slab) : T;
+    const int kt_begin = SEG ? 0 : slab * kt_per_slab;
+    const int kt_end = SEG ? (t_lim - t_base + TK - 1) / TK : min(kt_begin + kt_per_slab, nk_all);
 
     f32x4 acc[NJ][MI];  // [j: q-tile][i: p-tile]
 #pragma unroll
@@ -644,11 +650,11 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
         for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (kt_begin < kt_end) {
-        stage_tn<BP, NW>(U, ldu, kt_begin * TK, T, p0, P, smem, wave, lane);
+        stage_tn<BP, NW>(U, ldu, t_base + kt_begin * TK, t_lim, p0, P, smem, wave, lane);
         if (PATCH)
             stage_tn_patch<BQ, NW>(V, pg, kt_begin * TK, q0, smem + TK * BP, wave, lane);
         else
-            stage_tn<BQ, NW>(V, ldv, kt_begin * TK, T, q0, Q, smem + TK * BP, wave, lane);
+            stage_tn<BQ, NW>(V, ldv, t_base + kt_begin * TK, t_lim, q0, Q, smem + TK * BP, wave, lane);
     }
     __syncthreads();
     for (int kt = kt_begin; kt < kt_end; ++kt) {
@@ -657,11 +663,11 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
         bf16_t* Vs = Us + TK * BP;
         if (kt + 1 < kt_end) {
             bf16_t* Un = smem + (b ^ 1) * STAGE;
-            stage_tn<BP, NW>(U, ldu, (kt + 1) * TK, T, p0, P, Un, wave, lane);
+            stage_tn<BP, NW>(U, ldu, t_base + (kt + 1) * TK, t_lim, p0, P, Un, wave, lane);
             if (PATCH)
                 stage_tn_patch<BQ, NW>(V, pg, (kt + 1) * TK, q0, Un + TK * BP, wave, lane);
             else
-                stage_tn<BQ, NW>(V, ldv, (kt + 1) * TK, T, q0, Q, Un + TK * BP, wave, lane);
+                stage_tn<BQ, NW>(V, ldv, t_base + (kt + 1) * TK, t_lim, q0, Q, Un + TK * BP, wave, lane);
         }
 #pragma unroll
         for (int ks = 0; ks < TK / 32; ++ks) {
@@ -677,6 +683,26 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[j], fu[i], acc[j][i], 0, 0, 0);
         }
         __syncthreads();
+    }
+    if (SEG) {
+        // rows and columns past P, Q were staged as zeros, so the whole tile can be summed
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sq = fmaf(acc[j][i][r], acc[j][i][r], sq);
+        sq = wave_sum(sq);
+        float* red = reinterpret_cast<float*>(smem);       // the staging buffers are free after the last barrier
+        if (lane == 0) red[wave] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float t = 0.f;
+            for (int w = 0; w < NW; ++w) t += red[w];
+            C[(long long)slab * tiles_pq + tile] = t;
+        }
+        return;
     }
     // acc[j][i][r] = C[p = p0 + wp*WTP + i*16 + fr][q = q0 + wq*WTQ + j*16 + 4*fg + r]
     float* out = C + (long long)slab * slab_stride;
@@ -1202,6 +1228,32 @@ static int launch_tn_fast(int P, int Q, int T, const void* U, long long ldu, con
     if (pick_tn_cfg(P, Q) >= 1)
         return launch_tn_cfg<PATCH, 256, 256, 2, 4>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s);
     return launch_tn_cfg<PATCH, 128, 128, 2, 2>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s);
+}
+
+// per-segment tile sums of squares: partial[seg][tile]; returns the number of tiles per segment through *tiles
+template <int BT, int WP, int WQ>
+static int launch_tn_seg(int P, int Q, int T, int seg, const void* U, long long ldu, const void* V, long long ldv,
+                         float* partial, int* tiles, hipStream_t s) {
+    static unsigned long long done = 0;
+    constexpr size_t lds = 2 * (size_t)TK * (BT + BT) * sizeof(bf16_t);
+    auto fn = gemm_tn_fast_kernel<false, BT, BT, WP, WQ, true>;
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
+    if (rc != VITMI_OK) return rc;
+    const int tiles_p = ceil_div(P, BT), tiles_q = ceil_div(Q, BT), nseg = ceil_div(T, seg);
+    *tiles = tiles_p * tiles_q;
+    hipLaunchKernelGGL(fn, dim3(tiles_p * tiles_q * nseg), dim3(64 * WP * WQ), lds, s, (const bf16_t*)U, ldu,
+                       (const bf16_t*)V, ldv, partial, 0ll, 0ll, P, Q, T, tiles_q, tiles_p * tiles_q, seg, PatchGeom{});
+    VITMI_LAUNCH_CHECK("vitmi_gemm_wgrad_sqnorm(tn segments)");
+    return VITMI_OK;
+}
+int vitmi_gemm_tn_seg_tiles(int P, int Q) {
+    const int bt = (P >= 512 && Q >= 512) ? 256 : 128;
+    return ceil_div(P, bt) * ceil_div(Q, bt);
+}
+int vitmi_gemm_tn_seg_sq(int P, int Q, int T, int seg, const void* U, long long ldu, const void* V, long long ldv,
+                         float* partial, int* tiles, hipStream_t s) {
+    if (P >= 512 && Q >= 512) return launch_tn_seg<256, 2, 4>(P, Q, T, seg, U, ldu, V, ldv, partial, tiles, s);
+    return launch_tn_seg<128, 2, 2>(P, Q, T, seg, U, ldu, V, ldv, partial, tiles, s);
 }
 
 int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,

@@ -1,0 +1,197 @@
+// Per-sample gradient norms for DP-SGD (defence_method/DPSGD.py:114-136 clips every sample's gradient to
+// l2_norm_clip before summing).  The reference obtains per-sample gradients by running the batch one image at
+// a time; here one backward over the whole batch accumulates ||g_i||^2 per image without materialising g_i:
+// rows of the [tokens, features] activations are cut into segments of `seg` consecutive rows (one image each)
+// and every routine adds its parameter's share to sqnorm[segment].  Each sqnorm entry has one writer per
+// launch and all reductions run in a fixed order, so the norms are reproducible.
+#include "common.h"
+
+int vitmi_gemm_tn_seg_tiles(int P, int Q);
+int vitmi_gemm_tn_seg_sq(int P, int Q, int T, int seg, const void* U, long long ldu, const void* V, long long ldv,
+                         float* partial, int* tiles, hipStream_t s);
+bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const void* V, long long ldv, const void* C,
+                           long long ldc);
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// sqnorm[s] += sum over tiles of partial[s][tile]
+__global__ void seg_tile_sum_kernel(const float* __restrict__ partial, int tiles, int nseg, float* __restrict__ sqnorm) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg) return;
+    float t = 0.f;
+    for (int i = 0; i < tiles; ++i) t += partial[(long long)s * tiles + i];
+    sqnorm[s] += t;
+}
+
+// sqnorm[s] += sum of squares of a dense matrix of n elements (one block; the fallback path)
+__global__ __launch_bounds__(256) void dense_sq_accum_kernel(const float* __restrict__ x, long long n, float* __restrict__ dst) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) acc = fmaf(x[i], x[i], acc);
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) *dst += acc;
+}
+
+// sqnorm[s] += || sum_{t in segment s} x[t, :] ||^2
+template <typename T>
+__global__ __launch_bounds__(256) void seg_colsum_sq_kernel(const T* __restrict__ x, long long ld, long long rows, int cols,
+                                                           int seg, float* __restrict__ sqnorm) {
+    __shared__ float red[4];
+    const long long r0 = (long long)blockIdx.x * seg;
+    const long long r1 = r0 + seg < rows ? r0 + seg : rows;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float s = 0.f;
+        for (long long t = r0; t < r1; ++t) s += to_f32(x[t * ld + c]);
+        acc = fmaf(s, s, acc);
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) sqnorm[blockIdx.x] += acc;
+}
+
+// sqnorm[s] += || sum_t dy[t,:] * xhat[t,:] ||^2 + || sum_t dy[t,:] ||^2, xhat = (x - mean) * rstd: the LayerNorm
+// weight and bias gradients of one image
+template <typename T>
+__global__ __launch_bounds__(256) void seg_ln_sq_kernel(const T* __restrict__ dy, const T* __restrict__ x, long long ldx,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       long long rows, int D, int seg, float* __restrict__ sqnorm) {
+    __shared__ float red[4];
+    const long long r0 = (long long)blockIdx.x * seg;
+    const long long r1 = r0 + seg < rows ? r0 + seg : rows;
+    float acc = 0.f;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float sg = 0.f, sb = 0.f;
+        for (long long t = r0; t < r1; ++t) {
+            const float d = to_f32(dy[t * D + c]);
+            sg = fmaf(d, (to_f32(x[t * ldx + c]) - mean[t]) * rstd[t], sg);
+            sb += d;
+        }
+        acc = fmaf(sg, sg, fmaf(sb, sb, acc));
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) sqnorm[blockIdx.x] += acc;
+}
+
+// sqnorm[s] += sum over the segment's rows and all columns of x^2
+template <typename T>
+__global__ __launch_bounds__(256) void seg_sq_kernel(const T* __restrict__ x, long long ld, long long rows, int cols, int seg,
+                                                    float* __restrict__ sqnorm) {
+    __shared__ float red[4];
+    const long long r0 = (long long)blockIdx.x * seg;
+    const long long r1 = r0 + seg < rows ? r0 + seg : rows;
+    float acc = 0.f;
+    for (long long t = r0; t < r1; ++t)
+        for (int c = threadIdx.x; c < cols; c += 256) {
+            const float v = to_f32(x[t * ld + c]);
+            acc = fmaf(v, v, acc);
+        }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) sqnorm[blockIdx.x] += acc;
+}
+
+bool fast_seg_ok(int dt, int P, int Q, const void* U, long long ldu, const void* V, long long ldv) {
+    // the alignment rules of the direct-to-LDS tn kernel; the output pointer plays no part in segment mode
+    alignas(16) static const char dummy[16] = {0};
+    return dt == VITMI_BF16 && vitmi_gemm_tn_fast_ok(P, Q, U, ldu, V, ldv, dummy, (long long)((Q + 3) & ~3));
+}
+
+}  // namespace
+
+extern "C" long long vitmi_wgrad_sqnorm_workspace_bytes(int dt, int P, int Q, int T, int seg) {
+    if (P <= 0 || Q <= 0 || T <= 0 || seg <= 0) return 0;
+    const long long nseg = (T + seg - 1) / seg;
+    const long long fast = nseg * vitmi_gemm_tn_seg_tiles(P, Q) * (long long)sizeof(float);
+    const long long slow = (long long)P * Q * (long long)sizeof(float) + vitmi_gemm_wgrad_workspace_bytes(dt, P, Q, seg) + 256;
+    return (fast > slow ? fast : slow) + 256;
+}
+
+extern "C" int vitmi_wgrad_sqnorm(int dt, int P, int Q, int T, int seg, const void* U, long long ldu, const void* V,
+                                  long long ldv, float* sqnorm, void* workspace, void* stream) {
+    VITMI_CHECK_ARG(U && V && sqnorm && workspace, "vitmi_wgrad_sqnorm: null pointer");
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_wgrad_sqnorm: bad dtype %d", dt);
+    VITMI_CHECK_ARG(P > 0 && Q > 0 && T > 0 && seg > 0 && ldu >= P && ldv >= Q, "vitmi_wgrad_sqnorm: bad shape");
+    hipStream_t s = as_stream(stream);
+    const int nseg = (T + seg - 1) / seg;
+    if (fast_seg_ok(dt, P, Q, U, ldu, V, ldv)) {
+        int tiles = 0;
+        int rc = vitmi_gemm_tn_seg_sq(P, Q, T, seg, U, ldu, V, ldv, (float*)workspace, &tiles, s);
+        if (rc != VITMI_OK) return rc;
+        hipLaunchKernelGGL(seg_tile_sum_kernel, dim3(ceil_div(nseg, 256)), dim3(256), 0, s, (const float*)workspace, tiles,
+                           nseg, sqnorm);
+        VITMI_LAUNCH_CHECK("vitmi_wgrad_sqnorm");
+        return VITMI_OK;
+    }
+    // any dtype, any alignment: the segment's gradient through the ordinary weight-gradient product, then its norm
+    const long long es = dt == VITMI_F32 ? 4 : 2;
+    float* g = (float*)workspace;
+    void* ws2 = (char*)workspace + (((long long)P * Q * 4 + 255) & ~255ll);
+    for (int i = 0; i < nseg; ++i) {
+        const int len = (i + 1) * seg <= T ? seg : T - i * seg;
+        int rc = vitmi_gemm_wgrad(dt, P, Q, len, (const char*)U + (long long)i * seg * ldu * es, ldu,
+                                  (const char*)V + (long long)i * seg * ldv * es, ldv, g, Q, ws2, stream);
+        if (rc != VITMI_OK) return rc;
+        hipLaunchKernelGGL(dense_sq_accum_kernel, dim3(1), dim3(256), 0, s, g, (long long)P * Q, sqnorm + i);
+    }
+    VITMI_LAUNCH_CHECK("vitmi_wgrad_sqnorm");
+    return VITMI_OK;
+}
+
+#define SEG_ARGS_OK(who)                                                                             \
+    VITMI_CHECK_ARG(x && sqnorm, who ": null pointer");                                            \
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, who ": bad dtype %d", dt);                \
+    VITMI_CHECK_ARG(rows > 0 && cols > 0 && seg > 0 && ld >= cols, who ": bad shape")
+
+extern "C" int vitmi_seg_colsum_sqnorm(const void* x, int dt, long long rows, int cols, long long ld, int seg,
+                                       float* sqnorm, void* stream) {
+    SEG_ARGS_OK("vitmi_seg_colsum_sqnorm");
+    hipStream_t s = as_stream(stream);
+    const int nseg = (int)((rows + seg - 1) / seg);
+    if (dt == VITMI_F32)
+        hipLaunchKernelGGL((seg_colsum_sq_kernel<float>), dim3(nseg), dim3(256), 0, s, (const float*)x, ld, rows, cols, seg,
+                           sqnorm);
+    else
+        hipLaunchKernelGGL((seg_colsum_sq_kernel<bf16_t>), dim3(nseg), dim3(256), 0, s, (const bf16_t*)x, ld, rows, cols,
+                           seg, sqnorm);
+    VITMI_LAUNCH_CHECK("vitmi_seg_colsum_sqnorm");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_seg_sqnorm(const void* x, int dt, long long rows, int cols, long long ld, int seg, float* sqnorm,
+                                void* stream) {
+    SEG_ARGS_OK("vitmi_seg_sqnorm");
+    hipStream_t s = as_stream(stream);
+    const int nseg = (int)((rows + seg - 1) / seg);
+    if (dt == VITMI_F32)
+        hipLaunchKernelGGL((seg_sq_kernel<float>), dim3(nseg), dim3(256), 0, s, (const float*)x, ld, rows, cols, seg, sqnorm);
+    else
+        hipLaunchKernelGGL((seg_sq_kernel<bf16_t>), dim3(nseg), dim3(256), 0, s, (const bf16_t*)x, ld, rows, cols, seg,
+                           sqnorm);
+    VITMI_LAUNCH_CHECK("vitmi_seg_sqnorm");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_seg_layernorm_sqnorm(const void* dy, const void* x, long long ldx, const float* mean,
+                                          const float* rstd, int dt, long long rows, int D, int seg, float* sqnorm,
+                                          void* stream) {
+    VITMI_CHECK_ARG(dy && x && mean && rstd && sqnorm, "vitmi_seg_layernorm_sqnorm: null pointer");
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_seg_layernorm_sqnorm: bad dtype %d", dt);
+    VITMI_CHECK_ARG(rows > 0 && D > 0 && seg > 0 && ldx >= D, "vitmi_seg_layernorm_sqnorm: bad shape");
+    hipStream_t s = as_stream(stream);
+    const int nseg = (int)((rows + seg - 1) / seg);
+    if (dt == VITMI_F32)
+        hipLaunchKernelGGL((seg_ln_sq_kernel<float>), dim3(nseg), dim3(256), 0, s, (const float*)dy, (const float*)x, ldx,
+                           mean, rstd, rows, D, seg, sqnorm);
+    else
+        hipLaunchKernelGGL((seg_ln_sq_kernel<bf16_t>), dim3(nseg), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, ldx,
+                           mean, rstd, rows, D, seg, sqnorm);
+    VITMI_LAUNCH_CHECK("vitmi_seg_layernorm_sqnorm");
+    return VITMI_OK;
+}

@@ -1,0 +1,87 @@
+"""Batched DP-SGD gradient for the drop-in ViT modules.
+
+defence_method/DPSGD.py:111-136 runs the batch one image at a time to obtain per-sample gradients, clips each
+to `l2_norm_clip`, adds Gaussian noise of standard deviation `noise_multiplier * l2_norm_clip` and divides by
+the batch size.  (As written that loop zeroes the gradient inside the per-sample loop and clips nothing; the
+algorithm it intends is the one implemented here and by `literal_step`.)
+
+`clipped_noised_gradients` produces the same gradient from ONE forward over the whole batch and two backward
+passes over its graph:
+  1. the backward of sum_i loss_i with every parameter-gradient product replaced by its per-image squared norm
+     (`ops.per_sample_norms`: the weight-gradient MFMA kernel with its token slabs cut at image boundaries, each
+     block reducing its tile to a sum of squares) -> ||g_i|| for every image, no per-sample gradient in memory;
+  2. the ordinary backward of sum_i c_i loss_i with c_i = min(1, C / (||g_i|| + 1e-6)) -> sum_i c_i g_i.
+"""
+import torch
+
+from . import ops
+
+
+def per_sample_losses(logits, labels):
+    """loss_i of nn.CrossEntropyLoss on a batch of one (DPSGD.py:119-120)."""
+    return torch.nn.functional.cross_entropy(logits, labels, reduction="none")
+
+
+def per_sample_grad_norms(model, losses):
+    """||g_i||_2 over all parameters of `model` for losses [B] computed from one batched forward.  Keeps the graph."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    held = [p.grad for p in params]
+    for p in params:
+        p.grad = None
+    with ops.per_sample_norms(losses.shape[0], losses.device) as ps:
+        losses.sum().backward(retain_graph=True)
+    leaked = [n for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+    for p, g in zip(params, held):
+        p.grad = g
+    if leaked:
+        raise RuntimeError("per-sample norms: parameters reached outside the HIP autograd nodes: " + ", ".join(leaked))
+    return ps.sq.sqrt()
+
+
+def clipped_noised_gradients(model, inputs, labels, l2_norm_clip=1.0, noise_multiplier=1.0, generator=None,
+                             loss_fn=per_sample_losses, **forward_kwargs):
+    """Leaves (sum_i clip(g_i) + N(0, (noise_multiplier * l2_norm_clip)^2)) / B in every parameter's .grad
+    (DPSGD.py:122-127) and returns (mean loss, per-sample norms)."""
+    B = inputs.shape[0]
+    logits = model(inputs, **forward_kwargs)
+    losses = loss_fn(logits, labels)
+    if losses.shape != (B,):
+        raise ValueError("loss_fn must return one loss per sample")
+    norms = per_sample_grad_norms(model, losses)
+    coef = torch.clamp(l2_norm_clip / (norms + 1e-6), max=1.0)
+    for p in model.parameters():
+        p.grad = None
+    (losses * coef).sum().backward()
+    std = noise_multiplier * l2_norm_clip
+    for p in model.parameters():
+        if p.grad is None:
+            continue
+        if std > 0:
+            noise = torch.empty_like(p.grad).normal_(0, std, generator=generator)
+            p.grad = (p.grad + noise) / B
+        else:
+            p.grad = p.grad / B
+    return losses.detach().mean(), norms
+
+
+def literal_step_gradients(model, inputs, labels, l2_norm_clip=1.0, noise_multiplier=1.0, generator=None,
+                           **forward_kwargs):
+    """The same gradient by the reference's schedule: B passes of batch one (DPSGD.py:115-123)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    B = inputs.shape[0]
+    acc = [torch.zeros_like(p) for p in params]
+    norms = []
+    for i in range(B):
+        for p in params:
+            p.grad = None
+        torch.nn.functional.cross_entropy(model(inputs[i:i + 1], **forward_kwargs), labels[i:i + 1]).backward()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads]))
+        norms.append(norm)
+        torch._foreach_add_(acc, torch._foreach_mul(grads, torch.clamp(l2_norm_clip / (norm + 1e-6), max=1.0)))
+    std = noise_multiplier * l2_norm_clip
+    for p, a in zip(params, acc):
+        if std > 0:
+            a = a + torch.empty_like(a).normal_(0, std, generator=generator)
+        p.grad = a / B
+    return torch.stack(norms)

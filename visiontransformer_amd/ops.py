@@ -327,6 +327,71 @@ def patch_weighted_mean(x, p, weight):
     return out
 
 
+# ---------------------------------------------------------------------------------------------
+# per-sample gradient norms (DP-SGD): a backward pass run inside `per_sample_norms` adds every parameter's share
+# of ||g_i||^2 to .sq[i] and hands autograd no parameter gradients; input gradients flow as usual
+# ---------------------------------------------------------------------------------------------
+_PS = None
+
+
+class per_sample_norms:
+    def __init__(self, batch, device):
+        self.batch = int(batch)
+        self.sq = torch.zeros(self.batch, dtype=torch.float32, device=device)
+
+    def __enter__(self):
+        global _PS
+        if _PS is not None:
+            raise RuntimeError("per_sample_norms does not nest")
+        _PS = self
+        return self
+
+    def __exit__(self, *exc):
+        global _PS
+        _PS = None
+        return False
+
+    def seg(self, rows):
+        if rows % self.batch:
+            raise ValueError(f"{rows} rows do not split into {self.batch} samples")
+        return rows // self.batch
+
+
+def ps_weight(ps, dy2, x2):
+    """|| dy_i^T x_i ||_F^2 of y = x W^T, per sample."""
+    rows, P = dy2.shape
+    Q = x2.shape[1]
+    seg = ps.seg(rows)
+    if seg == 1:            # one row per sample: the gradient is an outer product, its norm a product of norms
+        a = torch.zeros_like(ps.sq)
+        b = torch.zeros_like(ps.sq)
+        check(lib.vitmi_seg_sqnorm(_p(dy2), _dt(dy2), rows, P, dy2.stride(0), 1, _p(a), _stream()), "vitmi_seg_sqnorm")
+        check(lib.vitmi_seg_sqnorm(_p(x2), _dt(x2), rows, Q, x2.stride(0), 1, _p(b), _stream()), "vitmi_seg_sqnorm")
+        ps.sq.addcmul_(a, b)
+        return
+    dt = _dt(dy2)
+    ws = _ws(lib.vitmi_wgrad_sqnorm_workspace_bytes(dt, P, Q, rows, seg), dy2.device)
+    check(lib.vitmi_wgrad_sqnorm(dt, P, Q, rows, seg, _p(dy2), dy2.stride(0), _p(x2), x2.stride(0), _p(ps.sq), _p(ws),
+                                 _stream()), "vitmi_wgrad_sqnorm")
+
+
+def ps_bias(ps, dy2):
+    rows, cols = dy2.shape
+    check(lib.vitmi_seg_colsum_sqnorm(_p(dy2), _dt(dy2), rows, cols, dy2.stride(0), ps.seg(rows), _p(ps.sq), _stream()),
+          "vitmi_seg_colsum_sqnorm")
+
+
+def ps_layernorm(ps, dy2, x2, mean, rstd):
+    rows, D = x2.shape
+    dy2 = dy2.contiguous()
+    check(lib.vitmi_seg_layernorm_sqnorm(_p(dy2), _p(x2), x2.stride(0), _p(mean), _p(rstd), _dt(x2), rows, D, ps.seg(rows),
+                                         _p(ps.sq), _stream()), "vitmi_seg_layernorm_sqnorm")
+
+
+def ps_rows(ps, x2, cols, ld, rows, seg):
+    check(lib.vitmi_seg_sqnorm(_p(x2), _dt(x2), rows, cols, ld, seg, _p(ps.sq), _stream()), "vitmi_seg_sqnorm")
+
+
 _block_ws_bytes = {}     # workspace sizes of the whole-block calls, by shape
 
 
@@ -391,6 +456,20 @@ class PatchEmbedFn(torch.autograd.Function):
         B, C, H, W, p, per = ctx.geom
         D = weight.shape[0]
         dy = dy.contiguous()
+        ps = _PS
+        if ps is not None:
+            if ctx.in_place:
+                patches = torch.empty((B * per, C * p * p), dtype=ctx.cdt, device=x.device)
+                check(lib.vitmi_patchify(_p(x), _dt(x), _p(patches), _dt(ctx.cdt), B, C, H, W, p, _stream()),
+                      "vitmi_patchify")
+            else:
+                patches = x
+            ps_weight(ps, dy.view(B * per, D), patches)
+            if ctx.has_bias:
+                ps_bias(ps, dy.view(B * per, D))
+            if ctx.needs_input_grad[0]:
+                raise NotImplementedError("per-sample norms with a gradient into the images")
+            return None, None, None, None
         if ctx.in_place:
             dw = torch.empty((D, C * p * p), dtype=torch.float32, device=x.device)
             ws = _ws(lib.vitmi_patch_embed_bwd_w_workspace_bytes(_dt(dy), B, C, H, W, p, D), x.device)
@@ -433,6 +512,14 @@ class TokensFn(torch.autograd.Function):
     def backward(ctx, dx):
         dx = dx.contiguous()
         B, N, D = dx.shape
+        ps = _PS
+        if ps is not None:
+            ps_rows(ps, dx, D, N * D, B, 1)                             # class token: row 0 of every image
+            if ctx.pe_shape is not None:
+                if ctx.seq_ord is not None:
+                    raise NotImplementedError("per-sample norms with a masked positional gather")
+                ps_rows(ps, dx, D, D, B * N, N)                         # table row r takes dx[i, r]
+            return dx[:, 1:, :], None, None, None
         dcls = torch.empty(D, dtype=torch.float32, device=dx.device)
         rows = ctx.pe_shape[0] if ctx.pe_shape is not None else 0
         dpe = torch.empty((rows, D), dtype=torch.float32, device=dx.device) if rows else None
@@ -461,6 +548,12 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, g, mean, rstd = ctx.saved_tensors
+        ps = _PS
+        if ps is not None:
+            dy2 = _as2d(dy.contiguous())
+            ps_layernorm(ps, dy2, x2, mean, rstd)
+            dx, _, _ = layernorm_bwd(dy2, x2, g, mean, rstd, need_affine=False)
+            return dx.view(ctx.shape), None, None, None
         dx, dg, db = layernorm_bwd(_as2d(dy.contiguous()), x2, g, mean, rstd)
         return dx.view(ctx.shape), dg.to(ctx.pdtype), db.to(ctx.pdtype), None
 
@@ -494,6 +587,12 @@ class LinearFn(torch.autograd.Function):
         dx = linear_bwd_x(dy2, w_c, w_t=weight_t(weight, ctx.cdt)).view(ctx.in_shape)
         if dx.dtype != ctx.in_dtype:
             dx = cast(dx, ctx.in_dtype)
+        ps = _PS
+        if ps is not None:
+            ps_weight(ps, dy2, x2)
+            if ctx.has_bias:
+                ps_bias(ps, dy2)
+            return dx, None, None, None, None
         dw = linear_bwd_w(dy2, x2).to(weight.dtype)
         db = colsum(dy2).to(weight.dtype) if ctx.has_bias else None
         return dx, dw, db, None, None
@@ -568,6 +667,31 @@ class AttnBlockFn(torch.autograd.Function):
         dy2 = _as2d(dy.contiguous())
         if dy2.dtype != cdt:
             dy2 = cast(dy2, cdt)
+        ps = _PS
+        if ps is not None:
+            xn_ = xn if xn is not None else x2
+            o2 = o.view(B * N, inner)
+            if w_out is not None:
+                ps_weight(ps, dy2, o2)
+                if has_bo:
+                    ps_bias(ps, dy2)
+                do = linear_bwd_x(dy2, compute_copy(w_out, cdt), w_t=weight_t(w_out, cdt))
+            else:
+                do = dy2
+            dqkv2 = attn_bwd(qkv, o, do.view(B, N, inner), lse, B, N, heads, dh).view(B * N, 3 * inner)
+            ps_weight(ps, dqkv2, xn_)
+            if ctx.bqkv_dtype is not None:
+                ps_bias(ps, dqkv2)
+            dxn = linear_bwd_x(dqkv2, compute_copy(w_qkv, cdt), w_t=weight_t(w_qkv, cdt))
+            if has_ln:
+                ps_layernorm(ps, dxn, x2, mean, rstd)
+                dx, _, _ = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None, need_affine=False)
+            else:
+                dx = add(dxn, dy2) if add_residual else dxn
+            dx = dx.view(B, N, D)
+            if dx.dtype != in_dtype:
+                dx = cast(dx, in_dtype)
+            return (dx,) + (None,) * 11
         if ctx.whole and dy2.is_contiguous():
             rows, dev, f32 = B * N, x2.device, torch.float32
             dx = torch.empty((rows, D), dtype=cdt, device=dev)
@@ -673,6 +797,24 @@ class FFBlockFn(torch.autograd.Function):
         dy2 = _as2d(dy.contiguous())
         if dy2.dtype != cdt:
             dy2 = cast(dy2, cdt)
+        ps = _PS
+        if ps is not None:
+            xn_ = xn if xn is not None else x2
+            ps_weight(ps, dy2, h)
+            ps_bias(ps, dy2)
+            du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u, w_t=weight_t(w2, cdt))
+            ps_weight(ps, du, xn_)
+            ps_bias(ps, du)
+            dxn = linear_bwd_x(du, compute_copy(w1, cdt), w_t=weight_t(w1, cdt))
+            if has_ln:
+                ps_layernorm(ps, dxn, x2, mean, rstd)
+                dx, _, _ = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None, need_affine=False)
+            else:
+                dx = add(dxn, dy2) if add_residual else dxn
+            dx = dx.view(shape)
+            if dx.dtype != in_dtype:
+                dx = cast(dx, in_dtype)
+            return (dx,) + (None,) * 9
         if ctx.whole and dy2.is_contiguous():
             rows, D = x2.shape
             M = w1.shape[0]
