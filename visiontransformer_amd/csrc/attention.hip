@@ -93,17 +93,45 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int seq0, int col0,
     return u.v;
 }
 
-// stage rows [0,NP) of a [seq][DH] HBM matrix (row stride ld) into an image; rows >= n and the
-// padding columns of a narrow head are zero
+// stage rows [0,NP) of two [seq][DH] HBM matrices (row strides lda, ldb) into their images; rows >= n and the
+// padding columns of a narrow head are zero.  Every load of the thread is issued before the first LDS write, so a
+// workgroup pays one HBM round trip for its operands rather than one per 16-byte chunk.  blockDim.x = ATTN_THREADS.
 template <int DH, int NP>
-__device__ __forceinline__ void stage_img(const bf16_t* src, long long ld, int n, bf16_t* img) {
+__device__ __forceinline__ void stage_img2(const bf16_t* a, long long lda, bf16_t* img_a, const bf16_t* b, long long ldb,
+                                           bf16_t* img_b, int n) {
     using A = AttnDims<DH>;
-    for (int c = threadIdx.x; c < NP * A::CPR; c += blockDim.x) {
+    constexpr int TOT = NP * A::CPR;
+    constexpr int IT = (TOT + ATTN_THREADS - 1) / ATTN_THREADS;
+    bf16x8 va[IT], vb[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int c = (int)threadIdx.x + i * ATTN_THREADS;
         const int r = c / A::CPR, kc = c % A::CPR;
-        bf16x8 v = zero8();
-        if (r < n && kc * 8 < DH) v = *reinterpret_cast<const bf16x8*>(src + (long long)r * ld + kc * 8);
-        *reinterpret_cast<bf16x8*>(img + img_off<DH>(r, kc)) = v;
+        va[i] = zero8();
+        vb[i] = zero8();
+        if (c < TOT && r < n && kc * 8 < DH) {
+            va[i] = *reinterpret_cast<const bf16x8*>(a + (long long)r * lda + kc * 8);
+            vb[i] = *reinterpret_cast<const bf16x8*>(b + (long long)r * ldb + kc * 8);
+        }
     }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int c = (int)threadIdx.x + i * ATTN_THREADS;
+        const int r = c / A::CPR, kc = c % A::CPR;
+        if (c < TOT) {
+            *reinterpret_cast<bf16x8*>(img_a + img_off<DH>(r, kc)) = va[i];
+            *reinterpret_cast<bf16x8*>(img_b + img_off<DH>(r, kc)) = vb[i];
+        }
+    }
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  This returns the (image, head) pair index a block
+// works on such that each XCD walks a contiguous range of pairs: the heads of one image, whose q/k/v rows are
+// adjacent 128-byte pieces of the same qkv rows, are then fetched by one XCD's L2 close together in time.
+__device__ __forceinline__ int xcd_block_order() {
+    const int G = gridDim.x, x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int q = G >> 3, rem = G & 7;
+    return x * q + (x < rem ? x : rem) + slot;
 }
 
 // ================================================================ forward (bf16)
@@ -111,7 +139,7 @@ __device__ __forceinline__ void stage_img(const bf16_t* src, long long ld, int n
 // values that feed P V.  Chunks of 32 keys that lie wholly beyond N are skipped, only the chunk
 // that straddles N pays for the key mask; exponentials are raw v_exp_f32.
 template <int DH, int NC, bool EXPORT>
-__global__ __launch_bounds__(ATTN_THREADS) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, bf16_t* __restrict__ probs, int N,
                                                             int H, float scale) {
     using A = AttnDims<DH>;
@@ -119,25 +147,30 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_fwd_bf16_kernel(const bf16_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vs = Ks + NP * A::W;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int blk = xcd_block_order();
+    const int b = blk / H, h = blk % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
     const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
     const bf16_t* kb = qb + I;
     const bf16_t* vb = qb + 2 * I;
-    stage_img<DH, NP>(kb, ld, N, Ks);
-    stage_img<DH, NP>(vb, ld, N, Vs);
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
+    bf16x8 qf[A::KS], qnext[A::KS];                   // the wave's first query tile travels beside the K, V staging
+#pragma unroll
+    for (int ks = 0; ks < A::KS; ++ks) qnext[ks] = global_frag<DH>(qb, ld, wave * 16 + fr, N, ks, fg);
+    stage_img2<DH, NP>(kb, ld, Ks, vb, ld, Vs, N);
+    __syncthreads();
+
     const float sl2 = scale * LOG2E;
-    const int nc_act = (N + 31) >> 5;                 // chunks that hold at least one real key
+    constexpr int nc_act = NC;                        // the launcher picks NC = ceil(N / 32): every chunk holds a real key
     for (int qt = wave; qt * 16 < N; qt += nwaves) {
         const int q = qt * 16 + fr;
-        bf16x8 qf[A::KS];
 #pragma unroll
-        for (int ks = 0; ks < A::KS; ++ks) qf[ks] = global_frag<DH>(qb, ld, q, N, ks, fg);
+        for (int ks = 0; ks < A::KS; ++ks) {          // the next tile's queries load under this tile's arithmetic
+            qf[ks] = qnext[ks];
+            qnext[ks] = global_frag<DH>(qb, ld, q + nwaves * 16, N, ks, fg);
+        }
         // S^T tiles: s[c][u][r] = score(query q, key 32c + 8fg + 4u + r)
         f32x4 s[NC][2];
         float mx = -INFINITY;
@@ -164,6 +197,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_fwd_bf16_kernel(const bf16_
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     mx = fmaxf(fmaxf(mx, fmaxf(s[c][u][0], s[c][u][1])), fmaxf(s[c][u][2], s[c][u][3]));
+                if (c & 1) __builtin_amdgcn_sched_barrier(0);   // keep the K fragment reads of later chunks from piling up in registers
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -216,6 +250,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_fwd_bf16_kernel(const bf16_
                 for (int dt = 0; dt < A::DT; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Vs, 32 * c, dt * 16, lane), pf, o[dt],
                                                                     0, 0, 0);
+                if (c & 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (q < N) {
@@ -249,7 +284,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
     float* lse2 = reinterpret_cast<float*>(dOs + NP * A::W);
     float* delta = lse2 + NP;
 
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int blk = xcd_block_order();
+    const int b = blk / H, h = blk % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
     const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
@@ -257,8 +293,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
     const bf16_t* vb = qb + 2 * I;
     const bf16_t* ob = out + (long long)b * N * I + h * DH;
     const bf16_t* dob = dout + (long long)b * N * I + h * DH;
-    stage_img<DH, NP>(qb, ld, N, Qs);
-    stage_img<DH, NP>(dob, I, N, dOs);
+    stage_img2<DH, NP>(qb, ld, Qs, dob, I, dOs, N);
     // lse (in log2 units) and delta = rowsum(dO * O) per query; padded queries get p = 0
     for (int q = threadIdx.x; q < NP; q += blockDim.x) {
         float l2 = 1e30f, dl = 0.f;
@@ -279,7 +314,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const float sl2 = scale * LOG2E;
-    const int nc_act = (N + 31) >> 5;
+    constexpr int nc_act = NC;                        // the launcher picks NC = ceil(N / 32)
     for (int kt = wave; kt * 16 < N; kt += nwaves) {
         const int key = kt * 16 + fr;
         bf16x8 kf[A::KS], vf[A::KS];
@@ -356,7 +391,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dq_bf16_kernel(const bf
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vs = Ks + NP * A::W;
 
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int blk = xcd_block_order();
+    const int b = blk / H, h = blk % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
     const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
@@ -364,29 +400,49 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dq_bf16_kernel(const bf
     const bf16_t* vb = qb + 2 * I;
     const bf16_t* ob = out + (long long)b * N * I + h * DH;
     const bf16_t* dob = dout + (long long)b * N * I + h * DH;
-    stage_img<DH, NP>(kb, ld, N, Ks);
-    stage_img<DH, NP>(vb, ld, N, Vs);
-    __syncthreads();
-
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
+    // the wave's first query tile (q, dO, O, lse) travels beside the K, V staging; later tiles load one tile ahead
+    bf16x8 qf[A::KS], dof[A::KS], qn[A::KS], don[A::KS], on[A::KS];
+    float lsen;
+    {
+        const int q = wave * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) {
+            qn[ks] = global_frag<DH>(qb, ld, q, N, ks, fg);
+            don[ks] = global_frag<DH>(dob, I, q, N, ks, fg);
+            on[ks] = global_frag<DH>(ob, I, q, N, ks, fg);
+        }
+        lsen = q < N ? lse[((long long)b * H + h) * N + q] : 1e30f;
+    }
+    stage_img2<DH, NP>(kb, ld, Ks, vb, ld, Vs, N);
+    __syncthreads();
+
     const float sl2 = scale * LOG2E;
-    const int nc_act = (N + 31) >> 5;
+    constexpr int nc_act = NC;                        // the launcher picks NC = ceil(N / 32)
     for (int qt = wave; qt * 16 < N; qt += nwaves) {
         const int q = qt * 16 + fr;
-        bf16x8 qf[A::KS], dof[A::KS];
         float dl = 0.f;
 #pragma unroll
         for (int ks = 0; ks < A::KS; ++ks) {
-            qf[ks] = global_frag<DH>(qb, ld, q, N, ks, fg);
-            dof[ks] = global_frag<DH>(dob, I, q, N, ks, fg);
-            const bf16x8 of = global_frag<DH>(ob, I, q, N, ks, fg);
+            qf[ks] = qn[ks];
+            dof[ks] = don[ks];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dl += (float)of[j] * (float)dof[ks][j];
+            for (int j = 0; j < 8; ++j) dl += (float)on[ks][j] * (float)dof[ks][j];
         }
         dl += __shfl_xor(dl, 16, 64);
         dl += __shfl_xor(dl, 32, 64);
-        const float l2 = q < N ? lse[((long long)b * H + h) * N + q] * LOG2E : 1e30f;
+        const float l2 = q < N ? lsen * LOG2E : 1e30f;
+        {
+            const int q2 = q + nwaves * 16;
+#pragma unroll
+            for (int ks = 0; ks < A::KS; ++ks) {
+                qn[ks] = global_frag<DH>(qb, ld, q2, N, ks, fg);
+                don[ks] = global_frag<DH>(dob, I, q2, N, ks, fg);
+                on[ks] = global_frag<DH>(ob, I, q2, N, ks, fg);
+            }
+            lsen = q2 < N ? lse[((long long)b * H + h) * N + q2] : 1e30f;
+        }
         f32x4 dqt[A::DT];
 #pragma unroll
         for (int dt = 0; dt < A::DT; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -441,7 +497,8 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
     float* Vs = Ks + (long long)N * (DH + 1);          // [N][DH+1]
     float* qs = Vs + (long long)N * (DH + 1);          // [4][DH]
     float* ps = qs + 4 * DH;                           // [4][N]
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int blk = xcd_block_order();
+    const int b = blk / H, h = blk % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
     const float* qb = qkv + (long long)b * N * ld + h * DH;
@@ -511,7 +568,8 @@ __global__ __launch_bounds__(256) void attn_bwd_q_f32_kernel(const float* __rest
     float* Vs = Ks + (long long)N * (DH + 1);
     float* qs = Vs + (long long)N * (DH + 1);   // [4][2*DH]: q row then dO row
     float* ds = qs + 4 * 2 * DH;                // [4][N]
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int blk = xcd_block_order();
+    const int b = blk / H, h = blk % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
     const float* qb = qkv + (long long)b * N * ld + h * DH;
@@ -581,7 +639,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_f32_kernel(const float* __res
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Qs = reinterpret_cast<float*>(smem);     // [N][DH+1]
     float* dOs = Qs + (long long)N * (DH + 1);      // [N][DH+1]
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int blk = xcd_block_order();
+    const int b = blk / H, h = blk % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
     const float* qb = qkv + (long long)b * N * ld + h * DH;
@@ -612,7 +671,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_f32_kernel(const float* __res
 // ---------------------------------------------------------------- dispatch helpers
 inline int pick_nc(int N) {
     const int need = (N + 31) / 32;
-    const int avail[] = {2, 3, 4, 7, 8};
+    const int avail[] = {1, 2, 3, 4, 5, 6, 7, 8};
     for (int a : avail)
         if (need <= a) return a;
     return 0;
@@ -687,9 +746,12 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
 
 #define DISPATCH_NC(FN, DH, ...)                      \
     switch (nc) {                                     \
+        case 1: return FN<DH, 1>(__VA_ARGS__);        \
         case 2: return FN<DH, 2>(__VA_ARGS__);        \
         case 3: return FN<DH, 3>(__VA_ARGS__);        \
         case 4: return FN<DH, 4>(__VA_ARGS__);        \
+        case 5: return FN<DH, 5>(__VA_ARGS__);        \
+        case 6: return FN<DH, 6>(__VA_ARGS__);        \
         case 7: return FN<DH, 7>(__VA_ARGS__);        \
         default: return FN<DH, 8>(__VA_ARGS__);       \
     }
