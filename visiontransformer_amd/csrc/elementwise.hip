@@ -278,7 +278,7 @@ __global__ void layernorm_fwd_kernel(const T* __restrict__ x, long long ldx, con
 // registers, and the block writes one partial row pair; a second kernel adds the partials in
 // block order.
 template <typename T, int V, int LN_MAX_ITERS>
-__global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long long ldx,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, long long ldx,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ rstd, const T* __restrict__ dres, T* __restrict__ dx,
                                      float* __restrict__ partial, long long rows, int D, int want_rsum) {
@@ -291,27 +291,53 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
         for (int j = 0; j < V; ++j) dg[it][j] = db[it][j] = gm[it][j] = dr[it][j] = 0.f;
         if (c < D) load_vec<float, V>(gamma + c, gm[it]);
     }
-    for (long long row = (long long)blockIdx.x * nw + wave; row < rows; row += (long long)gridDim.x * nw) {
-        const T* xr = x + row * ldx;
-        const T* dyr = dy + row * (long long)D;
-        const float mu = mean[row], rs = rstd[row];
-        float xh[LN_MAX_ITERS][V], g[LN_MAX_ITERS][V];
+    // The row loop runs one row ahead: the three loads of the next row (x, dy and the residual gradient) are in
+    // flight while the current row is reduced and stored, so a wave always has a row's worth of reads outstanding.
+    typedef Vec<T, V> __attribute__((aligned(sizeof(T) * V))) VT;
+    VT nx[LN_MAX_ITERS], ndy[LN_MAX_ITERS], ndr[LN_MAX_ITERS];
+    float nmu = 0.f, nrs = 0.f;
+    const long long stride = (long long)gridDim.x * nw;
+    auto fetch = [&](long long row) {
+#pragma unroll
+        for (int it = 0; it < LN_MAX_ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
+            if (c < D) {
+                nx[it] = *reinterpret_cast<const VT*>(x + row * ldx + c);
+                ndy[it] = *reinterpret_cast<const VT*>(dy + row * (long long)D + c);
+                if (dres) ndr[it] = *reinterpret_cast<const VT*>(dres + row * (long long)D + c);
+            }
+        }
+        nmu = mean[row];
+        nrs = rstd[row];
+    };
+    long long row = (long long)blockIdx.x * nw + wave;
+    if (row < rows) fetch(row);
+    for (; row < rows; row += stride) {
+        VT cx[LN_MAX_ITERS], cdy[LN_MAX_ITERS], cdr[LN_MAX_ITERS];
+#pragma unroll
+        for (int it = 0; it < LN_MAX_ITERS; ++it) {
+            cx[it] = nx[it];
+            cdy[it] = ndy[it];
+            cdr[it] = ndr[it];
+        }
+        const float mu = nmu, rs = nrs;
+        if (row + stride < rows) fetch(row + stride);
+        // the normalised input and the scaled gradient are recomputed from the raw row in the second pass rather
+        // than held: the registers go to the row in flight
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < LN_MAX_ITERS; ++it) {
             const int c = (it * 64 + lane) * V;
             if (c < D) {
-                float xv[V], dv[V];
-                load_vec<T, V>(xr + c, xv);
-                load_vec<T, V>(dyr + c, dv);
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    xh[it][j] = (xv[j] - mu) * rs;
-                    g[it][j] = dv[j] * gm[it][j];
-                    s1 += g[it][j];
-                    s2 += g[it][j] * xh[it][j];
-                    dg[it][j] += dv[j] * xh[it][j];
-                    db[it][j] += dv[j];
+                    const float dv = to_f32(cdy[it].v[j]);
+                    const float xh = (to_f32(cx[it].v[j]) - mu) * rs;
+                    const float g = dv * gm[it][j];
+                    s1 += g;
+                    s2 += g * xh;
+                    dg[it][j] += dv * xh;
+                    db[it][j] += dv;
                 }
             }
         }
@@ -323,14 +349,17 @@ __global__ void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restri
             if (c < D) {
                 float o[V];
 #pragma unroll
-                for (int j = 0; j < V; ++j) o[j] = rs * (g[it][j] - c1 - xh[it][j] * c2);
+                for (int j = 0; j < V; ++j) {
+                    const float xh = (to_f32(cx[it].v[j]) - mu) * rs;
+                    const float g = to_f32(cdy[it].v[j]) * gm[it][j];
+                    o[j] = rs * (g - c1 - xh * c2);
+                }
                 if (dres) {
-                    float r[V];
-                    load_vec<T, V>(dres + row * (long long)D + c, r);
 #pragma unroll
                     for (int j = 0; j < V; ++j) {
-                        o[j] += r[j];
-                        dr[it][j] += r[j];
+                        const float r = to_f32(cdr[it].v[j]);
+                        o[j] += r;
+                        dr[it][j] += r;
                     }
                 }
                 store_vec<T, V>(dxr + c, o);
@@ -406,10 +435,11 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_final_kernel(const float* 
     }
 }
 
-// enough blocks for ~16 waves per CU on 256 CUs: the kernel streams 3-4 row-sized tensors
+// three 4-wave blocks per CU on 256 CUs (the backward kernel's registers allow three waves per SIMD), every wave
+// with the loads of two rows outstanding: the kernel streams 3-4 row-sized tensors
 inline int ln_bwd_blocks(long long rows) {
     long long b = (rows + 3) / 4;
-    if (b > 1024) b = 1024;
+    if (b > 768) b = 768;
     if (b < 1) b = 1;
     return (int)b;
 }
