@@ -25,6 +25,7 @@ namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int ATTN_THREADS = 512;  // 8 waves per (image, head) workgroup
+constexpr size_t LDS_BYTES = 160 * 1024;
 
 __device__ __forceinline__ bf16x8 zero8() {
     bf16x8 z;
@@ -96,16 +97,16 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int seq0, int col0,
 // stage rows [0,NP) of two [seq][DH] HBM matrices (row strides lda, ldb) into their images; rows >= n and the
 // padding columns of a narrow head are zero.  Every load of the thread is issued before the first LDS write, so a
 // workgroup pays one HBM round trip for its operands rather than one per 16-byte chunk.  blockDim.x = ATTN_THREADS.
-template <int DH, int NP>
+template <int DH, int NP, int THREADS = ATTN_THREADS>
 __device__ __forceinline__ void stage_img2(const bf16_t* a, long long lda, bf16_t* img_a, const bf16_t* b, long long ldb,
                                            bf16_t* img_b, int n) {
     using A = AttnDims<DH>;
     constexpr int TOT = NP * A::CPR;
-    constexpr int IT = (TOT + ATTN_THREADS - 1) / ATTN_THREADS;
+    constexpr int IT = (TOT + THREADS - 1) / THREADS;
     bf16x8 va[IT], vb[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int c = (int)threadIdx.x + i * ATTN_THREADS;
+        const int c = (int)threadIdx.x + i * THREADS;
         const int r = c / A::CPR, kc = c % A::CPR;
         va[i] = zero8();
         vb[i] = zero8();
@@ -116,7 +117,7 @@ __device__ __forceinline__ void stage_img2(const bf16_t* a, long long lda, bf16_
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
-        const int c = (int)threadIdx.x + i * ATTN_THREADS;
+        const int c = (int)threadIdx.x + i * THREADS;
         const int r = c / A::CPR, kc = c % A::CPR;
         if (c < TOT) {
             *reinterpret_cast<bf16x8*>(img_a + img_off<DH>(r, kc)) = va[i];
@@ -134,12 +135,15 @@ __device__ __forceinline__ int xcd_block_order() {
     return x * q + (x < rem ? x : rem) + slot;
 }
 
+// elements of one wave's export tile buffer: 16 rows of N probabilities plus the alignment shift, in 16-byte units
+__host__ __device__ __forceinline__ int export_tile_elems(int N) { return (16 * N + 7 + 7) & ~7; }
+
 // ================================================================ forward (bf16)
 // EXPORT is a template flag of the same kernel: the exported probabilities are the very bf16
 // values that feed P V.  Chunks of 32 keys that lie wholly beyond N are skipped, only the chunk
 // that straddles N pays for the key mask; exponentials are raw v_exp_f32.
-template <int DH, int NC, bool EXPORT>
-__global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+template <int DH, int NC, bool EXPORT, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, bf16_t* __restrict__ probs, int N,
                                                             int H, float scale) {
     using A = AttnDims<DH>;
@@ -156,10 +160,13 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(4,
     const bf16_t* vb = qb + 2 * I;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
+    // export: the wave's 16 x N probability tile is assembled in LDS in its final layout (the 16 rows are one
+    // contiguous run of the [B,H,N,N] tensor) and written out with 16-byte stores
+    bf16_t* Pw = Vs + NP * A::W + wave * export_tile_elems(N);
     bf16x8 qf[A::KS], qnext[A::KS];                   // the wave's first query tile travels beside the K, V staging
 #pragma unroll
     for (int ks = 0; ks < A::KS; ++ks) qnext[ks] = global_frag<DH>(qb, ld, wave * 16 + fr, N, ks, fg);
-    stage_img2<DH, NP>(kb, ld, Ks, vb, ld, Vs, N);
+    stage_img2<DH, NP, THREADS>(kb, ld, Ks, vb, ld, Vs, N);
     __syncthreads();
 
     const float sl2 = scale * LOG2E;
@@ -221,6 +228,11 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(4,
         sum += __shfl_xor(sum, 32, 64);
         const float inv = __builtin_amdgcn_rcpf(sum);
         if (fg == 0 && q < N) lse[((long long)b * H + h) * N + q] = mx * scale + __logf(sum);
+        // the tile's first element in the export tensor; the LDS copy starts at the same offset modulo 16 bytes,
+        // so that 16-byte pieces of the tile are aligned on both sides
+        bf16_t* gtile = EXPORT ? probs + (((long long)b * H + h) * N + qt * 16) * N : nullptr;
+        const int mis = EXPORT ? (int)((reinterpret_cast<uintptr_t>(gtile) >> 1) & 7) : 0;
+        bf16_t* ptile = Pw + mis;
         // O^T = V^T P^T, d-tile by d-tile; V^T fragments come transposed out of the V row image
         f32x4 o[A::DT];
 #pragma unroll
@@ -234,16 +246,14 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pf[4 * u + r] = (bf16_t)(s[c][u][r] * inv);
                 if (EXPORT) {
-                    if (q < N) {
-                        bf16_t* prow = probs + (((long long)b * H + h) * N + q) * N + 32 * c + 8 * fg;
-                        if (32 * c + 32 <= N) {
+                    bf16_t* prow = ptile + fr * N + 32 * c + 8 * fg;
+                    if (32 * c + 32 <= N) {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) prow[j] = pf[j];
-                        } else {
+                        for (int j = 0; j < 8; ++j) prow[j] = pf[j];
+                    } else {
 #pragma unroll
-                            for (int j = 0; j < 8; ++j)
-                                if (32 * c + 8 * fg + j < N) prow[j] = pf[j];
-                        }
+                        for (int j = 0; j < 8; ++j)
+                            if (32 * c + 8 * fg + j < N) prow[j] = pf[j];
                     }
                 }
 #pragma unroll
@@ -252,6 +262,16 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(4,
                                                                     0, 0, 0);
                 if (c & 1) __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if (EXPORT) {
+            const int total = (N - qt * 16 < 16 ? N - qt * 16 : 16) * N;   // rows beyond N are left out
+            const int head = (8 - mis) & 7;                               // elements up to the first 16-byte boundary
+            if (lane < head && lane < total) gtile[lane] = ptile[lane];
+            const int pieces = total > head ? (total - head) >> 3 : 0;
+            for (int i = lane; i < pieces; i += 64)
+                *reinterpret_cast<bf16x8*>(gtile + head + 8 * i) = *reinterpret_cast<const bf16x8*>(ptile + head + 8 * i);
+            const int done = head + 8 * pieces;
+            if (done + lane < total) gtile[done + lane] = ptile[done + lane];
         }
         if (q < N) {
             bf16_t* orow = out + ((long long)b * N + q) * I + h * DH;
@@ -705,18 +725,34 @@ size_t fwd_smem() {
     return (size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t);
 }
 
-template <int DH, int NC, bool EXPORT>
-int launch_fwd_x(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
+template <int DH, int NC, bool EXPORT, int THREADS>
+int launch_fwd_t(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
     const float scale = 1.0f / sqrtf((float)DH);
     static unsigned long long done = 0;
-    const size_t sm = fwd_smem<DH, NC>();
-    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH, NC, EXPORT>), sm, &done,
+    // the export variant adds one tile buffer per wave
+    const size_t sm = fwd_smem<DH, NC>() + (EXPORT ? (size_t)(THREADS / 64) * export_tile_elems(N) * sizeof(bf16_t) : 0);
+    const size_t sm_max = THREADS > ATTN_THREADS ? LDS_BYTES
+                                                 : fwd_smem<DH, NC>() + (EXPORT ? (size_t)(THREADS / 64) * export_tile_elems(NC * 32) * sizeof(bf16_t) : 0);
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH, NC, EXPORT, THREADS>), sm_max, &done,
                         "vitmi_attn_fwd: LDS attribute");
     if (rc != VITMI_OK) return rc;
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC, EXPORT>), dim3(B * H), dim3(ATTN_THREADS), sm, s, (const bf16_t*)qkv,
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC, EXPORT, THREADS>), dim3(B * H), dim3(THREADS), sm, s, (const bf16_t*)qkv,
                        (bf16_t*)out, lse, (bf16_t*)probs, N, H, scale);
     VITMI_LAUNCH_CHECK("vitmi_attn_fwd(bf16)");
     return VITMI_OK;
+}
+
+// The export variant holds a 16 x N tile per wave in LDS, which leaves room for one workgroup per CU at ViT-B
+// lengths: it then runs 16 waves per workgroup (the occupancy of two 8-wave workgroups) when those tiles fit.
+template <int DH, int NC, bool EXPORT>
+int launch_fwd_x(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
+    if constexpr (EXPORT) {
+        const size_t one = fwd_smem<DH, NC>() + (size_t)(ATTN_THREADS / 64) * export_tile_elems(N) * sizeof(bf16_t);
+        const size_t wide = fwd_smem<DH, NC>() + (size_t)(2 * ATTN_THREADS / 64) * export_tile_elems(N) * sizeof(bf16_t);
+        if (2 * one > LDS_BYTES && wide <= LDS_BYTES)
+            return launch_fwd_t<DH, NC, EXPORT, 2 * ATTN_THREADS>(qkv, out, lse, probs, B, N, H, s);
+    }
+    return launch_fwd_t<DH, NC, EXPORT, ATTN_THREADS>(qkv, out, lse, probs, B, N, H, s);
 }
 
 template <int DH, int NC>
