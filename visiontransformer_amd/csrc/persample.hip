@@ -97,6 +97,100 @@ __global__ __launch_bounds__(256) void seg_sq_kernel(const T* __restrict__ x, lo
     if (threadIdx.x == 0) sqnorm[blockIdx.x] += acc;
 }
 
+// Wide variants of the two column-sum kernels for 16-byte aligned rows: one 8-wave block per segment.  A wave
+// owns a group of 64 * VEC consecutive columns (16 bytes per lane) and every R-th row of the segment; the R row
+// groups of a column group are added through LDS in row-group order, then squared and summed in wave order.
+template <typename T> struct SegVec { static constexpr int N = 16 / sizeof(T); T v[16 / sizeof(T)]; };
+constexpr int SEG_WAVES = 8;
+
+template <typename T, bool LN>
+__global__ __launch_bounds__(64 * SEG_WAVES) void seg_colsum_sq_wide_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                                            long long ld, long long ldx,
+                                                                            const float* __restrict__ mean,
+                                                                            const float* __restrict__ rstd, long long rows,
+                                                                            int cols, int seg, float* __restrict__ sqnorm) {
+    constexpr int VEC = SegVec<T>::N;
+    typedef SegVec<T> __attribute__((aligned(16))) VT;
+    __shared__ float part[SEG_WAVES][64 * VEC * (LN ? 2 : 1)];
+    __shared__ float red[SEG_WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * seg;
+    const long long r1 = r0 + seg < rows ? r0 + seg : rows;
+    const int ncg = (cols + 64 * VEC - 1) / (64 * VEC);
+    float total = 0.f;                                   // wave 0 .. P-1 accumulate their column groups' squares
+    for (int cg0 = 0; cg0 < ncg; cg0 += SEG_WAVES) {
+        const int P = ncg - cg0 < SEG_WAVES ? ncg - cg0 : SEG_WAVES;      // column groups in this pass
+        const int R = SEG_WAVES / P;                                       // row groups per column group
+        const int cg = wave % P, rg = wave / P;
+        const int c = ((cg0 + cg) * 64 + lane) * VEC;
+        float sb[VEC], sg[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sb[j] = sg[j] = 0.f;
+        if (rg < R && c < cols) {
+            long long t = r0 + rg;
+            for (; t + R < r1; t += 2 * R) {             // two rows in flight
+                const VT a = *reinterpret_cast<const VT*>(dy + t * ld + c);
+                const VT b = *reinterpret_cast<const VT*>(dy + (t + R) * ld + c);
+                if (LN) {
+                    const VT xa = *reinterpret_cast<const VT*>(x + t * ldx + c);
+                    const VT xb = *reinterpret_cast<const VT*>(x + (t + R) * ldx + c);
+                    const float ma = mean[t], ra = rstd[t], mb = mean[t + R], rb = rstd[t + R];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        sg[j] = fmaf(to_f32(a.v[j]), (to_f32(xa.v[j]) - ma) * ra, sg[j]);
+                        sg[j] = fmaf(to_f32(b.v[j]), (to_f32(xb.v[j]) - mb) * rb, sg[j]);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) sb[j] += to_f32(a.v[j]) + to_f32(b.v[j]);
+            }
+            if (t < r1) {
+                const VT a = *reinterpret_cast<const VT*>(dy + t * ld + c);
+                if (LN) {
+                    const VT xa = *reinterpret_cast<const VT*>(x + t * ldx + c);
+                    const float ma = mean[t], ra = rstd[t];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) sg[j] = fmaf(to_f32(a.v[j]), (to_f32(xa.v[j]) - ma) * ra, sg[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) sb[j] += to_f32(a.v[j]);
+            }
+        }
+        __syncthreads();                                 // the previous pass has read `part`
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            part[wave][lane * VEC + j] = sb[j];
+            if (LN) part[wave][64 * VEC + lane * VEC + j] = sg[j];
+        }
+        __syncthreads();
+        if (wave < P && c < cols) {                      // wave == cg here (rg == 0)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float b = 0.f, g = 0.f;
+                for (int r = 0; r < R; ++r) {
+                    b += part[r * P + wave][lane * VEC + j];
+                    if (LN) g += part[r * P + wave][64 * VEC + lane * VEC + j];
+                }
+                total = fmaf(b, b, total);
+                if (LN) total = fmaf(g, g, total);
+            }
+        }
+    }
+    total = wave_sum(total);
+    if (lane == 0) red[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < SEG_WAVES; ++w) t += red[w];
+        sqnorm[blockIdx.x] += t;
+    }
+}
+
+inline bool wide_ok(const void* p, long long ld, int cols, int dt) {
+    const int vec = dt == VITMI_F32 ? 4 : 8;
+    return (reinterpret_cast<uintptr_t>(p) % 16 == 0) && ld % vec == 0 && cols % vec == 0;
+}
+
 bool fast_seg_ok(int dt, int P, int Q, const void* U, long long ldu, const void* V, long long ldv) {
     // the alignment rules of the direct-to-LDS tn kernel; the output pointer plays no part in segment mode
     alignas(16) static const char dummy[16] = {0};
@@ -154,7 +248,16 @@ extern "C" int vitmi_seg_colsum_sqnorm(const void* x, int dt, long long rows, in
     SEG_ARGS_OK("vitmi_seg_colsum_sqnorm");
     hipStream_t s = as_stream(stream);
     const int nseg = (int)((rows + seg - 1) / seg);
-    if (dt == VITMI_F32)
+    if (wide_ok(x, ld, cols, dt) && seg >= 2 * SEG_WAVES) {
+        if (dt == VITMI_F32)
+            hipLaunchKernelGGL((seg_colsum_sq_wide_kernel<float, false>), dim3(nseg), dim3(64 * SEG_WAVES), 0, s,
+                               (const float*)x, (const float*)nullptr, ld, 0ll, (const float*)nullptr, (const float*)nullptr,
+                               rows, cols, seg, sqnorm);
+        else
+            hipLaunchKernelGGL((seg_colsum_sq_wide_kernel<bf16_t, false>), dim3(nseg), dim3(64 * SEG_WAVES), 0, s,
+                               (const bf16_t*)x, (const bf16_t*)nullptr, ld, 0ll, (const float*)nullptr,
+                               (const float*)nullptr, rows, cols, seg, sqnorm);
+    } else if (dt == VITMI_F32)
         hipLaunchKernelGGL((seg_colsum_sq_kernel<float>), dim3(nseg), dim3(256), 0, s, (const float*)x, ld, rows, cols, seg,
                            sqnorm);
     else
@@ -186,7 +289,14 @@ extern "C" int vitmi_seg_layernorm_sqnorm(const void* dy, const void* x, long lo
     VITMI_CHECK_ARG(rows > 0 && D > 0 && seg > 0 && ldx >= D, "vitmi_seg_layernorm_sqnorm: bad shape");
     hipStream_t s = as_stream(stream);
     const int nseg = (int)((rows + seg - 1) / seg);
-    if (dt == VITMI_F32)
+    if (wide_ok(dy, D, D, dt) && wide_ok(x, ldx, D, dt) && seg >= 2 * SEG_WAVES) {
+        if (dt == VITMI_F32)
+            hipLaunchKernelGGL((seg_colsum_sq_wide_kernel<float, true>), dim3(nseg), dim3(64 * SEG_WAVES), 0, s,
+                               (const float*)dy, (const float*)x, (long long)D, ldx, mean, rstd, rows, D, seg, sqnorm);
+        else
+            hipLaunchKernelGGL((seg_colsum_sq_wide_kernel<bf16_t, true>), dim3(nseg), dim3(64 * SEG_WAVES), 0, s,
+                               (const bf16_t*)dy, (const bf16_t*)x, (long long)D, ldx, mean, rstd, rows, D, seg, sqnorm);
+    } else if (dt == VITMI_F32)
         hipLaunchKernelGGL((seg_ln_sq_kernel<float>), dim3(nseg), dim3(256), 0, s, (const float*)dy, (const float*)x, ldx,
                            mean, rstd, rows, D, seg, sqnorm);
     else
