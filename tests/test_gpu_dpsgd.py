@@ -102,3 +102,25 @@ def test_noise_statistics_and_reproducibility():
     k = "transformer.layers.0.1.fn.net.0.weight"
     noise = (out[0][k] - clean[k]) * 8                                          # N(0, (2.0 * 1.0)^2)
     assert abs(noise.std().item() - 2.0) < 0.05 and abs(noise.mean().item()) < 0.05
+
+
+@pytest.mark.parametrize("P,Q,seg,nseg", [(512, 512, 70, 130), (768, 512, 197, 40), (128, 256, 33, 600), (96, 200, 17, 9)])
+def test_weight_gradient_norms_many_segments(P, Q, seg, nseg):
+    """vitmi_wgrad_sqnorm where a block walks several images (more images than one round of blocks has room for),
+    segments that are not multiples of the 64-token tile, a ragged last segment, and the unaligned fallback."""
+    from visiontransformer_amd import ops
+    gen = torch.Generator().manual_seed(P + seg)
+    T = seg * nseg - 5                                                      # the last image is 5 tokens short
+    dy = torch.randn(T, P, generator=gen).to(DEV).bfloat16()
+    x = torch.randn(T, Q, generator=gen).to(DEV).bfloat16()
+    with ops.per_sample_norms(nseg, DEV) as ps:
+        ps.seg = lambda rows: seg
+        ops.ps_weight(ps, dy, x)
+        got = ps.sq.clone()
+        ops.ps_weight(ps, dy, x)                                            # accumulates, bit for bit the same share
+        assert torch.equal(ps.sq, 2 * got)
+    want = torch.empty(nseg, dtype=torch.float64)
+    for i in range(nseg):
+        g = dy[i * seg:(i + 1) * seg].double().t() @ x[i * seg:(i + 1) * seg].double()
+        want[i] = (g * g).sum()
+    assert rel_err(got, want.float().to(DEV)) < 1e-4

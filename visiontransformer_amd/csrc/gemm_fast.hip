@@ -612,9 +612,10 @@ __device__ __forceinline__ bf16x8 frag_tn(const bf16_t* lds, int col0, int ks, i
 
 // BP x BQ output tile, WP x WQ waves, each wave (BP/WP) x (BQ/WQ); dynamic LDS = two stages of
 // [64 t][BP + BQ] bf16
-// SEG: the token axis is cut into segments of `kt_per_slab` TOKENS (one image each) instead of slabs of K-tiles,
-// and the block writes the sum of squares of its tile of the segment's product to C[segment * tiles + tile]
-// rather than the tile itself (per-sample weight-gradient norms).
+// SEG: the token axis is cut into segments of `kt_per_slab` TOKENS (one image each) instead of slabs of K-tiles;
+// the grid is tiles x segment groups, and a block writes, for every segment of its group, the sum of squares of
+// its tile of the segment's product to C[segment * tiles + tile] rather than the tile itself (per-sample
+// weight-gradient norms).
 template <bool PATCH, int BP, int BQ, int WP, int WQ, bool SEG = false>
 __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t* __restrict__ U, long long ldu,
                                                                     const bf16_t* __restrict__ V, long long ldv,
@@ -636,39 +637,13 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wp = wave / WQ, wq = wave % WQ;
     const int fr = lane & 15, fg = lane >> 4;
-    const int nk_all = (T + TK - 1) / TK;
-    // tokens [t_base + kt*TK, ...) for kt in [kt_begin, kt_end), none at or beyond t_lim
-    const int t_base = SEG ? slab * kt_per_slab : 0;
-    const int t_lim = SEG ? min(T, t_base + kt_per_slab) : T;
-    const int kt_begin = SEG ? 0 : slab * kt_per_slab;
-    const int kt_end = SEG ? (t_lim - t_base + TK - 1) / TK : min(kt_begin + kt_per_slab, nk_all);
-
     f32x4 acc[NJ][MI];  // [j: q-tile][i: p-tile]
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (kt_begin < kt_end) {
-        stage_tn<BP, NW>(U, ldu, t_base + kt_begin * TK, t_lim, p0, P, smem, wave, lane);
-        if (PATCH)
-            stage_tn_patch<BQ, NW>(V, pg, kt_begin * TK, q0, smem + TK * BP, wave, lane);
-        else
-            stage_tn<BQ, NW>(V, ldv, t_base + kt_begin * TK, t_lim, q0, Q, smem + TK * BP, wave, lane);
-    }
-    __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int b = (kt - kt_begin) & 1;
-        bf16_t* Us = smem + b * STAGE;
-        bf16_t* Vs = Us + TK * BP;
-        if (kt + 1 < kt_end) {
-            bf16_t* Un = smem + (b ^ 1) * STAGE;
-            stage_tn<BP, NW>(U, ldu, t_base + (kt + 1) * TK, t_lim, p0, P, Un, wave, lane);
-            if (PATCH)
-                stage_tn_patch<BQ, NW>(V, pg, (kt + 1) * TK, q0, Un + TK * BP, wave, lane);
-            else
-                stage_tn<BQ, NW>(V, ldv, t_base + (kt + 1) * TK, t_lim, q0, Q, Un + TK * BP, wave, lane);
-        }
+    auto mfma_tile = [&](const bf16_t* Us, const bf16_t* Vs) {
 #pragma unroll
         for (int ks = 0; ks < TK / 32; ++ks) {
             bf16x8 fv[NJ], fu[MI];
@@ -682,27 +657,83 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
                 for (int j = 0; j < NJ; ++j)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[j], fu[i], acc[j][i], 0, 0, 0);
         }
+    };
+
+    if constexpr (SEG) {
+        // The block walks a contiguous group of segments with ONE two-stage pipeline: the K-tile sequence is
+        // (segment, 64-token tile) flattened, the last tile of a segment zero-masked past the segment's end.  When a
+        // segment's last tile has been multiplied the accumulators are reduced to a sum of squares and cleared.
+        const int seglen = kt_per_slab;
+        const int nseg = (T + seglen - 1) / seglen;
+        const int groups = gridDim.x / tiles_pq;
+        const int per = (nseg + groups - 1) / groups;
+        const int s_lo = slab * per, s_hi = min(nseg, s_lo + per);
+        const int ktps = (seglen + TK - 1) / TK;
+        const int n_it = s_hi > s_lo ? (s_hi - s_lo) * ktps : 0;
+        float* red = reinterpret_cast<float*>(smem + 2 * STAGE);        // [2][NW], beyond the two stages
+        auto stage = [&](int it, bf16_t* dst) {
+            const int sg = s_lo + it / ktps, kt = it % ktps;
+            const int tb = sg * seglen, tl = min(T, tb + seglen);
+            stage_tn<BP, NW>(U, ldu, tb + kt * TK, tl, p0, P, dst, wave, lane);
+            stage_tn<BQ, NW>(V, ldv, tb + kt * TK, tl, q0, Q, dst + TK * BP, wave, lane);
+        };
+        if (n_it > 0) stage(0, smem);
         __syncthreads();
-    }
-    if (SEG) {
-        // rows and columns past P, Q were staged as zeros, so the whole tile can be summed
-        float sq = 0.f;
+        for (int it = 0; it < n_it; ++it) {
+            bf16_t* Us = smem + (it & 1) * STAGE;
+            if (it + 1 < n_it) stage(it + 1, smem + ((it + 1) & 1) * STAGE);
+            mfma_tile(Us, Us + TK * BP);
+            const bool last = (it % ktps) == ktps - 1;
+            const int sg = s_lo + it / ktps;
+            if (last) {
+                // rows and columns past P, Q were staged as zeros, so the whole tile can be summed
+                float sq = 0.f;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) sq = fmaf(acc[j][i][r], acc[j][i][r], sq);
-        sq = wave_sum(sq);
-        float* red = reinterpret_cast<float*>(smem);       // the staging buffers are free after the last barrier
-        if (lane == 0) red[wave] = sq;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float t = 0.f;
-            for (int w = 0; w < NW; ++w) t += red[w];
-            C[(long long)slab * tiles_pq + tile] = t;
+                        for (int r = 0; r < 4; ++r) sq = fmaf(acc[j][i][r], acc[j][i][r], sq);
+                        acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                sq = wave_sum(sq);
+                if (lane == 0) red[(sg & 1) * NW + wave] = sq;
+            }
+            __syncthreads();
+            if (last && threadIdx.x == 0) {
+                float t = 0.f;
+                for (int w = 0; w < NW; ++w) t += red[(sg & 1) * NW + w];
+                C[(long long)sg * tiles_pq + tile] = t;
+            }
         }
         return;
+    }
+
+    const int nk_all = (T + TK - 1) / TK;
+    const int kt_begin = slab * kt_per_slab;
+    const int kt_end = min(kt_begin + kt_per_slab, nk_all);
+    if (kt_begin < kt_end) {
+        stage_tn<BP, NW>(U, ldu, kt_begin * TK, T, p0, P, smem, wave, lane);
+        if (PATCH)
+            stage_tn_patch<BQ, NW>(V, pg, kt_begin * TK, q0, smem + TK * BP, wave, lane);
+        else
+            stage_tn<BQ, NW>(V, ldv, kt_begin * TK, T, q0, Q, smem + TK * BP, wave, lane);
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int b = (kt - kt_begin) & 1;
+        bf16_t* Us = smem + b * STAGE;
+        bf16_t* Vs = Us + TK * BP;
+        if (kt + 1 < kt_end) {
+            bf16_t* Un = smem + (b ^ 1) * STAGE;
+            stage_tn<BP, NW>(U, ldu, (kt + 1) * TK, T, p0, P, Un, wave, lane);
+            if (PATCH)
+                stage_tn_patch<BQ, NW>(V, pg, (kt + 1) * TK, q0, Un + TK * BP, wave, lane);
+            else
+                stage_tn<BQ, NW>(V, ldv, (kt + 1) * TK, T, q0, Q, Un + TK * BP, wave, lane);
+        }
+        mfma_tile(Us, Vs);
+        __syncthreads();
     }
     // acc[j][i][r] = C[p = p0 + wp*WTP + i*16 + fr][q = q0 + wq*WTQ + j*16 + 4*fg + r]
     float* out = C + (long long)slab * slab_stride;
@@ -1235,14 +1266,19 @@ template <int BT, int WP, int WQ>
 static int launch_tn_seg(int P, int Q, int T, int seg, const void* U, long long ldu, const void* V, long long ldv,
                          float* partial, int* tiles, hipStream_t s) {
     static unsigned long long done = 0;
-    constexpr size_t lds = 2 * (size_t)TK * (BT + BT) * sizeof(bf16_t);
+    constexpr size_t lds = 2 * (size_t)TK * (BT + BT) * sizeof(bf16_t) + 2 * WP * WQ * sizeof(float);
     auto fn = gemm_tn_fast_kernel<false, BT, BT, WP, WQ, true>;
     int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
     if (rc != VITMI_OK) return rc;
     const int tiles_p = ceil_div(P, BT), tiles_q = ceil_div(Q, BT), nseg = ceil_div(T, seg);
-    *tiles = tiles_p * tiles_q;
-    hipLaunchKernelGGL(fn, dim3(tiles_p * tiles_q * nseg), dim3(64 * WP * WQ), lds, s, (const bf16_t*)U, ldu,
-                       (const bf16_t*)V, ldv, partial, 0ll, 0ll, P, Q, T, tiles_q, tiles_p * tiles_q, seg, PatchGeom{});
+    const int ntiles = tiles_p * tiles_q;
+    *tiles = ntiles;
+    // one round of blocks (two per CU for the 128-wide tiles): each block walks `per` consecutive segments
+    const int want = (BT == 256 ? 256 : 512) / ntiles;
+    const int per = ceil_div(nseg, want < 1 ? 1 : want);
+    const int groups = ceil_div(nseg, per);
+    hipLaunchKernelGGL(fn, dim3(ntiles * groups), dim3(64 * WP * WQ), lds, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
+                       partial, 0ll, 0ll, P, Q, T, tiles_q, ntiles, seg, PatchGeom{});
     VITMI_LAUNCH_CHECK("vitmi_gemm_wgrad_sqnorm(tn segments)");
     return VITMI_OK;
 }
