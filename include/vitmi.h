@@ -284,6 +284,11 @@ int vitmi_meanpool_bwd(const void* dout, void* dx, int dt, int B, int N, int D, 
 /* y = a + b elementwise (dt); gradient accumulation on the residual stream. */
 int vitmi_add(const void* a, const void* b, void* y, int dt, long long n, void* stream);
 
+/* nn.Dropout in training mode (mymodel/ViT.py:68,70,90: after GELU, after the second MLP layer, after to_out):
+ * y[i] = x[i] * keep(i) / (1 - p) with keep(i) drawn from a counter-based generator keyed by (seed, i), so the
+ * backward pass is the same call on the gradient with the same seed and no mask is stored.  In place allowed. */
+int vitmi_dropout(const void* x, void* y, int dt, long long n, float p, unsigned long long seed, void* stream);
+
 /* Fused Adam step over one flat fp32 parameter tensor (torch.optim.Adam semantics with
  * weight_decay added to the gradient, trainer.py:204-205), optionally refreshing a bf16 copy
  * of the parameter in the same pass.  step is the 1-based step count. */

@@ -71,9 +71,14 @@ def attention(x, w_qkv, w_out, b_out, heads):
     return out, probs
 
 
-def feed_forward(x, w1, b1, w2, b2):
-    """mymodel/ViT.py:62-73: Linear -> GELU(erf) -> Linear (dropouts are p=0)."""
-    return gelu_erf(x @ w1.t() + b1) @ w2.t() + b2
+def feed_forward(x, w1, b1, w2, b2, keep_hidden=None, keep_out=None):
+    """mymodel/ViT.py:62-73: Linear -> GELU(erf) -> Dropout -> Linear -> Dropout.  A dropout is stated as the
+    multiplier tensor (0 or 1/(1-p) per element) the caller supplies; None = identity (p = 0 or eval mode)."""
+    h = gelu_erf(x @ w1.t() + b1)
+    if keep_hidden is not None:
+        h = h * keep_hidden
+    y = h @ w2.t() + b2
+    return y * keep_out if keep_out is not None else y
 
 
 def sinusoid_table(n, d, max_len=5000):
@@ -100,8 +105,10 @@ def depth_of(params):
     return d
 
 
-def transformer_block(x, params, i, heads, collect_probs=None):
-    """mymodel/ViT.py:117-121: x = attn(LN(x)) + x ; x = ff(LN(x)) + x."""
+def transformer_block(x, params, i, heads, collect_probs=None, keep=None):
+    """mymodel/ViT.py:117-121: x = attn(LN(x)) + x ; x = ff(LN(x)) + x.  keep: optional dropout multipliers
+    {(i, "attn_out"): [B,N,D] (ViT.py:90), (i, "hidden"): [B,N,M] (:68), (i, "ff_out"): [B,N,D] (:70)}."""
+    keep = keep or {}
     pre = f"transformer.layers.{i}."
     w_out = params.get(pre + "0.fn.to_out.0.weight")
     b_out = params.get(pre + "0.fn.to_out.0.bias")
@@ -109,15 +116,18 @@ def transformer_block(x, params, i, heads, collect_probs=None):
                          params[pre + "0.fn.to_qkv.weight"], w_out, b_out, heads)
     if collect_probs is not None:
         collect_probs.append(probs)
+    if (i, "attn_out") in keep:
+        a = a * keep[(i, "attn_out")]
     x = a + x
     f = feed_forward(layer_norm(x, params[pre + "1.norm.weight"], params[pre + "1.norm.bias"]),
                      params[pre + "1.fn.net.0.weight"], params[pre + "1.fn.net.0.bias"],
-                     params[pre + "1.fn.net.3.weight"], params[pre + "1.fn.net.3.bias"])
+                     params[pre + "1.fn.net.3.weight"], params[pre + "1.fn.net.3.bias"],
+                     keep.get((i, "hidden")), keep.get((i, "ff_out")))
     return f + x
 
 
 def forward_features(params, x, heads, unk_mask=None, train_method="mask", use_pe=True,
-                     collect_probs=None):
+                     collect_probs=None, keep=None):
     """Token sequence after the last block, [B,N,D].
 
     mymodel/ViT.py:151-162 when pos_embedding is 2-D [N,D];
@@ -162,14 +172,14 @@ def forward_features(params, x, heads, unk_mask=None, train_method="mask", use_p
     if use_pe:
         tok = tok + pos
     for i in range(depth_of(params)):
-        tok = transformer_block(tok, params, i, heads, collect_probs)
+        tok = transformer_block(tok, params, i, heads, collect_probs, keep)
     return tok
 
 
 def forward(params, x, heads, pool="cls", unk_mask=None, train_method="mask", use_pe=True,
-            collect_probs=None):
+            collect_probs=None, keep=None):
     """Logits [B,num_classes]: mymodel/ViT.py:164-168 on top of forward_features."""
-    tok = forward_features(params, x, heads, unk_mask, train_method, use_pe, collect_probs)
+    tok = forward_features(params, x, heads, unk_mask, train_method, use_pe, collect_probs, keep)
     feat = tok.mean(dim=1) if pool == "mean" else tok[:, 0]
     feat = layer_norm(feat, params["mlp_head.0.weight"], params["mlp_head.0.bias"])
     return feat @ params["mlp_head.1.weight"].t() + params["mlp_head.1.bias"]

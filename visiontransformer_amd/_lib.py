@@ -16,6 +16,7 @@ FAM_GEMM, FAM_ATTN_FWD, FAM_ATTN_BWD, FAM_LAYERNORM, FAM_TOKENS, FAM_OTHER = ran
 FAM_GEMM_VARIANT0, FAM_COUNT = 8, 29
 
 P, I, L, F = c_void_p, c_int, c_longlong, c_float
+U64 = ctypes.c_ulonglong
 
 # name -> (restype, argtypes); mirrors include/vitmi.h one to one
 SIGNATURES = {
@@ -71,6 +72,7 @@ SIGNATURES = {
     "vitmi_meanpool_fwd": (I, [P, P, I, I, I, I, P]),
     "vitmi_meanpool_bwd": (I, [P, P, I, I, I, I, P]),
     "vitmi_add": (I, [P, P, P, I, L, P]),
+    "vitmi_dropout": (I, [P, P, I, L, F, U64, P]),
     "vitmi_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, F, I, F, P]),
     "vitmi_adam_step_multi": (I, [P, I, P, I, I, F, F, F, F, F, I, F, P]),
 }

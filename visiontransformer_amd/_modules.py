@@ -108,12 +108,12 @@ class FeedForward(_HipModule):
         self.drop_p = dropout
 
     def _run(self, x, norm, add_residual):
-        if self.drop_p > 0 and self.training:
-            raise NotImplementedError("dropout > 0 inside the MLP block is not implemented in the HIP path")
         l1, l2 = self.net[0], self.net[3]
+        p = self.net[2].p                                   # the two nn.Dropout modules share the constructor's rate
+        drop = (p, ops.new_seed(), ops.new_seed()) if p > 0 and self.training else None
         return ops.FFBlockFn.apply(x, norm.weight if norm is not None else None,
                                    norm.bias if norm is not None else None, l1.weight, l1.bias, l2.weight, l2.bias,
-                                   norm.eps if norm is not None else 0.0, add_residual, self.compute_dtype)
+                                   norm.eps if norm is not None else 0.0, add_residual, self.compute_dtype, drop)
 
     def forward(self, x):
         return self._run(x, None, add_residual=False)
@@ -147,16 +147,20 @@ class Attention(_HipModule):
                 or len(self.attn_drop._forward_hooks) > 0)
 
     def _run(self, x, norm, add_residual):
-        if self.drop_p > 0 and self.training:
-            raise NotImplementedError("dropout > 0 inside the attention block is not implemented in the HIP path")
         if x.dim() != 3:
             raise ValueError(f"Attention expects [batch, tokens, dim], got {tuple(x.shape)}")
         proj = self.to_out[0] if isinstance(self.to_out, nn.Sequential) else None
         want = self._export_wanted()
+        # nn.Dropout after to_out (mymodel/ViT.py:90) sits between the projection and the residual add
+        p = self.to_out[1].p if proj is not None and self.training else 0.0
         y, probs = ops.AttnBlockFn.apply(
             x, norm.weight if norm is not None else None, norm.bias if norm is not None else None,
             self.to_qkv.weight, proj.weight if proj is not None else None, proj.bias if proj is not None else None,
-            self.heads, norm.eps if norm is not None else 0.0, add_residual, want, self.compute_dtype)
+            self.heads, norm.eps if norm is not None else 0.0, add_residual and p == 0, want, self.compute_dtype)
+        if p > 0:
+            y = ops.DropoutFn.apply(y, p, ops.new_seed())
+            if add_residual:
+                y = ops.AddFn.apply(y, x if x.dtype == y.dtype else _CastFn.apply(x, y.dtype))
         if want:
             self.last_probs = self.attn_drop(self.attend(probs))
         return y

@@ -219,6 +219,27 @@ __global__ void tokens_scatter_rows_kernel(const float* __restrict__ possum, con
     }
 }
 
+// ---------------------------------------------------------------- dropout
+// y[i] = x[i] * keep(i) / (1 - p), keep(i) = [u32(seed, i) >= p * 2^32]: a counter-based generator (two rounds of the
+// splitmix64 finaliser over seed and element index), so the backward pass regenerates the mask from the seed
+// instead of storing it.  One 64-bit draw serves two elements.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, unsigned long long seed,
+                               unsigned threshold, float scale) {
+    const long long pairs = (n + 1) >> 1;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < pairs; k += (long long)gridDim.x * blockDim.x) {
+        const unsigned long long r = mix64(mix64(seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(k + 1)) ^ seed);
+        const long long i = 2 * k;
+        y[i] = from_f32<T>((unsigned)r >= threshold ? to_f32(x[i]) * scale : 0.f);
+        if (i + 1 < n) y[i + 1] = from_f32<T>((unsigned)(r >> 32) >= threshold ? to_f32(x[i + 1]) * scale : 0.f);
+    }
+}
+
 // ---------------------------------------------------------------- LayerNorm
 // ITERS = ceil(D / (64*V)) is a template parameter so the per-lane row slice stays in registers.
 
@@ -715,6 +736,26 @@ extern "C" int vitmi_add(const void* a, const void* b, void* y, int dt, long lon
         }
     }
     VITMI_LAUNCH_CHECK("vitmi_add");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_dropout(const void* x, void* y, int dt, long long n, float p, unsigned long long seed, void* stream) {
+    VITMI_CHECK_ARG(n >= 0 && (n == 0 || (x && y)), "vitmi_dropout: null pointer or negative n");
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_dropout: bad dtype %d", dt);
+    VITMI_CHECK_ARG(p >= 0.f && p < 1.f, "vitmi_dropout: p = %f outside [0, 1)", (double)p);
+    if (n == 0) return VITMI_OK;
+    hipStream_t s = as_stream(stream);
+    const double t = (double)p * 4294967296.0;
+    const unsigned threshold = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    const float scale = 1.0f / (1.0f - p);
+    const int blocks = (int)std::min<long long>(((n + 1) / 2 + 255) / 256, 8192);
+    if (dt == VITMI_F32)
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, (float*)y, n, seed, threshold,
+                           scale);
+    else
+        hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, n, seed,
+                           threshold, scale);
+    VITMI_LAUNCH_CHECK("vitmi_dropout");
     return VITMI_OK;
 }
 

@@ -392,6 +392,46 @@ def ps_rows(ps, x2, cols, ld, rows, seg):
     check(lib.vitmi_seg_sqnorm(_p(x2), _dt(x2), rows, cols, ld, seg, _p(ps.sq), _stream()), "vitmi_seg_sqnorm")
 
 
+def dropout(x, p, seed, out=None):
+    """x * keep / (1 - p), the mask a function of (seed, element index); out=x works in place."""
+    x = x.contiguous()
+    y = torch.empty_like(x) if out is None else out
+    check(lib.vitmi_dropout(_p(x), _p(y), _dt(x), x.numel(), float(p), int(seed), _stream()), "vitmi_dropout")
+    return y
+
+
+def new_seed():
+    """A 63-bit seed from torch's CPU generator (so torch.manual_seed governs the dropout masks)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout in training mode (mymodel/ViT.py:68,70,90); the backward regenerates the mask from the seed."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        _need_gpu(x)
+        ctx.p, ctx.seed = p, seed
+        return dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
+class AddFn(torch.autograd.Function):
+    """Residual add (mymodel/ViT.py:119-120) as its own node, for the paths where it cannot ride on a GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _need_gpu(a, b)
+        return add(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
 _block_ws_bytes = {}     # workspace sizes of the whole-block calls, by shape
 
 
@@ -754,13 +794,14 @@ class FFBlockFn(torch.autograd.Function):
     """[LayerNorm ->] Linear -> GELU(erf) -> Linear [+ x]  (mymodel/ViT.py:58, 65-73, 120)."""
 
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, add_residual, cdt):
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, eps, add_residual, cdt, drop=None):
+        # drop = (p, seed_hidden, seed_out): nn.Dropout after GELU and after the second layer (mymodel/ViT.py:68,70)
         _need_gpu(x, w1)
         shape = x.shape
         x2 = _as2d(x)
         if x2.dtype != cdt:
             x2 = cast(x2, cdt)
-        whole = ln_w is not None and add_residual and x2.is_contiguous()
+        whole = ln_w is not None and add_residual and x2.is_contiguous() and drop is None
         if whole:                       # the usual pre-norm residual block: one foreign call for the three launches
             g = ln_w.detach().float()
             rows, D = x2.shape
@@ -784,8 +825,16 @@ class FFBlockFn(torch.autograd.Function):
                 g = mean = rstd = None
                 xn = x2
             h, u = linear_fwd(xn, compute_copy(w1, cdt), b1.detach().float(), epi=EPI_GELU, want_aux=True)
-            y, _ = linear_fwd(h, compute_copy(w2, cdt), b2.detach().float(), res=x2 if add_residual else None)
+            if drop is None:
+                y, _ = linear_fwd(h, compute_copy(w2, cdt), b2.detach().float(), res=x2 if add_residual else None)
+            else:
+                dropout(h, drop[0], drop[1], out=h)            # the saved h is the dropped one: dW2 = dy^T h
+                y, _ = linear_fwd(h, compute_copy(w2, cdt), b2.detach().float())
+                dropout(y, drop[0], drop[2], out=y)
+                if add_residual:
+                    y = add(y, x2.contiguous())
         ctx.whole = whole
+        ctx.drop = drop
         ctx.save_for_backward(x2, g, mean, rstd, xn if ln_w is not None else None, u, h, w1, w2)
         ctx.meta = (shape, add_residual, cdt, ln_w is not None, ln_w.dtype if ln_w is not None else None, x.dtype)
         return y.view(*shape[:-1], w2.shape[0])
@@ -798,6 +847,30 @@ class FFBlockFn(torch.autograd.Function):
         if dy2.dtype != cdt:
             dy2 = cast(dy2, cdt)
         ps = _PS
+        drop = ctx.drop
+        if drop is not None:
+            if ps is not None:
+                raise NotImplementedError("per-sample norms through a block with dropout")
+            if xn is None:
+                xn = x2
+            dyd = dropout(dy2, drop[0], drop[2])
+            dw2 = linear_bwd_w(dyd, h).to(w2.dtype)
+            db2 = colsum(dyd).to(w2.dtype)
+            du = linear_bwd_x(dyd, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u, w_t=weight_t(w2, cdt))
+            dropout(du, drop[0], drop[1], out=du)
+            dw1 = linear_bwd_w(du, xn).to(w1.dtype)
+            db1 = colsum(du).to(w1.dtype)
+            dxn = linear_bwd_x(du, compute_copy(w1, cdt), w_t=weight_t(w1, cdt))
+            dg = db = None
+            if has_ln:
+                dx, dg, db = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None)
+                dg, db = dg.to(ln_dtype), db.to(ln_dtype)
+            else:
+                dx = add(dxn, dy2) if add_residual else dxn
+            dx = dx.view(shape)
+            if dx.dtype != in_dtype:
+                dx = cast(dx, in_dtype)
+            return dx, dg, db, dw1, db1, dw2, db2, None, None, None, None
         if ps is not None:
             xn_ = xn if xn is not None else x2
             ps_weight(ps, dy2, h)
@@ -814,7 +887,7 @@ class FFBlockFn(torch.autograd.Function):
             dx = dx.view(shape)
             if dx.dtype != in_dtype:
                 dx = cast(dx, in_dtype)
-            return (dx,) + (None,) * 9
+            return (dx,) + (None,) * 10
         if ctx.whole and dy2.is_contiguous():
             rows, D = x2.shape
             M = w1.shape[0]
@@ -836,7 +909,7 @@ class FFBlockFn(torch.autograd.Function):
             if dx.dtype != in_dtype:
                 dx = cast(dx, in_dtype)
             return (dx, dg.to(ln_dtype), db.to(ln_dtype), dw1.to(w1.dtype), db1.to(w1.dtype), dw2.to(w2.dtype),
-                    db2.to(w2.dtype), None, None, None)
+                    db2.to(w2.dtype), None, None, None, None)
         if xn is None:
             xn = x2
         dw2 = linear_bwd_w(dy2, h).to(w2.dtype)
@@ -860,7 +933,7 @@ class FFBlockFn(torch.autograd.Function):
         dx = dx.view(shape)
         if dx.dtype != in_dtype:
             dx = cast(dx, in_dtype)
-        return dx, dg, db, dw1, db1, dw2, db2, None, None, None
+        return dx, dg, db, dw1, db1, dw2, db2, None, None, None, None
 
 
 class MeanPoolFn(torch.autograd.Function):

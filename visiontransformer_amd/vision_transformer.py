@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._modules import LayerNorm, Linear, PatchEmbed as _PatchEmbedBase, ProbsTap, _HipModule
+from ._modules import LayerNorm, Linear, PatchEmbed as _PatchEmbedBase, ProbsTap, _CastFn, _HipModule
 
 __all__ = ["Attention", "Mlp", "Block", "PatchEmbed", "VisionTransformer", "vit_small_patch16_224",
            "vit_base_patch16_224", "vit_tiny_patch16_224"]
@@ -62,13 +62,19 @@ class Attention(_HipModule):
         return self.fused_attn is False or len(self.attn_drop._forward_hooks) > 0
 
     def _run(self, x, norm, add_residual):
-        if self.drop_p > 0 and self.training:
-            raise NotImplementedError("dropout > 0 inside the attention block is not implemented in the HIP path")
+        if self.attn_drop.p > 0 and self.training:
+            raise NotImplementedError("dropout on the attention probabilities (attn_drop > 0) is not implemented in "
+                                      "the HIP path")
         want = self._export_wanted()
+        p = self.proj_drop.p if self.training else 0.0       # proj_drop sits between the projection and the residual
         y, probs = ops.AttnBlockFn.apply(
             x, norm.weight if norm is not None else None, norm.bias if norm is not None else None,
             self.qkv.weight, self.proj.weight, self.proj.bias, self.num_heads,
-            norm.eps if norm is not None else 0.0, add_residual, want, self.compute_dtype, self.qkv.bias)
+            norm.eps if norm is not None else 0.0, add_residual and p == 0, want, self.compute_dtype, self.qkv.bias)
+        if p > 0:
+            y = ops.DropoutFn.apply(y, p, ops.new_seed())
+            if add_residual:
+                y = ops.AddFn.apply(y, x if x.dtype == y.dtype else _CastFn.apply(x, y.dtype))
         if want:
             self.last_probs = self.attn_drop(probs)
         return y
@@ -94,12 +100,12 @@ class Mlp(_HipModule):
         self.drop_p = drop
 
     def _run(self, x, norm, add_residual):
-        if self.drop_p > 0 and self.training:
-            raise NotImplementedError("dropout > 0 inside the MLP block is not implemented in the HIP path")
+        p = self.drop1.p
+        drop = (p, ops.new_seed(), ops.new_seed()) if p > 0 and self.training else None
         return ops.FFBlockFn.apply(x, norm.weight if norm is not None else None,
                                    norm.bias if norm is not None else None, self.fc1.weight, self.fc1.bias,
                                    self.fc2.weight, self.fc2.bias, norm.eps if norm is not None else 0.0,
-                                   add_residual, self.compute_dtype)
+                                   add_residual, self.compute_dtype, drop)
 
     def forward(self, x):
         return self._run(x, None, add_residual=False)
