@@ -89,15 +89,21 @@ __global__ void colsum_partial_kernel(const T* __restrict__ x, long long rows, i
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
     if (c0 < cols) {
-        for (long long r = r_begin + wave; r < r_end; r += 4) {
-            if (V > 1) {
-                float f[V];
-                load_vec<T, V>(x + r * ld + c0, f);
+        // four rows per trip, their loads independent of one another: a wave keeps four requests in flight
+        // instead of paying one memory round trip per row
+        long long r = r_begin + wave;
+        for (; r + 12 < r_end; r += 16) {
+            float f[4][V];
 #pragma unroll
-                for (int j = 0; j < V; ++j) acc[j] += f[j];
-            } else {
-                acc[0] += to_f32(x[r * ld + c0]);
-            }
+            for (int u = 0; u < 4; ++u) load_vec<T, V>(x + (r + 4 * u) * ld + c0, f[u]);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += (f[0][j] + f[1][j]) + (f[2][j] + f[3][j]);
+        }
+        for (; r < r_end; r += 4) {
+            float f[V];
+            load_vec<T, V>(x + r * ld + c0, f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] += f[j];
         }
     }
     __shared__ float red[4][64 * V];
@@ -140,8 +146,8 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
 }
 
 inline int colsum_chunks(long long rows) {
-    long long c = (rows + 255) / 256;
-    if (c > 128) c = 128;
+    long long c = (rows + 63) / 64;
+    if (c > 512) c = 512;
     if (c < 1) c = 1;
     return (int)c;
 }

@@ -974,11 +974,20 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long long sl
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (; i < n4; i += stride) {
+        // slabs are added in index order; four loads are issued per trip so that they overlap
         f32x4 s = *reinterpret_cast<const f32x4*>(slabs + 4 * i);
-        for (int k = 1; k < nslabs; ++k) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(slabs + k * slab_stride + 4 * i);
-            s += v;
+        int k = 1;
+        for (; k + 3 < nslabs; k += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(slabs + k * slab_stride + 4 * i);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(slabs + (k + 1) * slab_stride + 4 * i);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(slabs + (k + 2) * slab_stride + 4 * i);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(slabs + (k + 3) * slab_stride + 4 * i);
+            s += v0;
+            s += v1;
+            s += v2;
+            s += v3;
         }
+        for (; k < nslabs; ++k) s += *reinterpret_cast<const f32x4*>(slabs + k * slab_stride + 4 * i);
         *reinterpret_cast<f32x4*>(out + 4 * i) = s;
     }
 }
