@@ -78,3 +78,46 @@ def test_trainer_style_step_with_data_parallel_wrappers_absent():
     model.eval()
     with torch.no_grad():
         assert model(inputs, unk_mask=None).shape == (48, 10)
+
+
+def test_graphed_forward_backward_matches_eager():
+    """One HIP graph of forward + loss + backward (visiontransformer_amd.graphs) leaves the same gradients and, with
+    the optimizer outside the graph, the same parameters as the eager step, bit for bit, with a new mask per step."""
+    from visiontransformer_amd import ViT_mask
+    from visiontransformer_amd.graphs import GraphedForwardBackward
+    from visiontransformer_amd.optim import FusedAdam
+    dev = torch.device("cuda", 0)
+    kw = dict(image_size=32, patch_size=4, embed_dim=64, num_classes=10, depth=2, heads=4, mlp_dim=128)
+    gen = torch.Generator().manual_seed(0)
+    xs = [torch.randn(16, 3, 32, 32, generator=gen).to(dev) for _ in range(4)]
+    ys = [torch.randint(0, 10, (16,), generator=gen).to(dev) for _ in range(4)]
+    masks = []
+    for _ in range(4):
+        um = torch.zeros(1, 65, dtype=torch.long)
+        um[0, torch.randperm(64, generator=gen)[:32] + 1] = 1
+        masks.append(um.to(dev))
+    ce = torch.nn.functional.cross_entropy
+
+    def make():
+        torch.manual_seed(3)
+        m = ViT_mask.VIT(**kw).to(dev).train()
+        m.train_method = "mask"
+        return m, FusedAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.99))
+
+    m1, o1 = make()
+    m2, o2 = make()
+    g = GraphedForwardBackward(m2, ce, xs[0], ys[0], masks[0])
+    for x, y, um in zip(xs, ys, masks):
+        o1.zero_grad()
+        l1 = ce(m1(x, unk_mask=um), y)
+        l1.backward()
+        l2 = g(x, y, um)
+        assert torch.equal(l1.detach(), l2.detach())
+        for (k, a), b in zip(m1.named_parameters(), m2.parameters()):
+            assert torch.equal(a.grad, b.grad), k
+        o1.step()
+        o2.step()
+    assert all(torch.equal(a, b) for a, b in zip(m1.parameters(), m2.parameters()))
+    m3 = ViT_mask.VIT(dropout=0.1, **kw).to(dev).train()
+    with pytest.raises(ValueError, match="dropout"):
+        GraphedForwardBackward(m3, ce, xs[0], ys[0], masks[0])

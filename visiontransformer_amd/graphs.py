@@ -1,0 +1,57 @@
+"""Forward + loss + backward of a drop-in model as one HIP graph.
+
+At the 32x32-pixel geometries of the reference's configs (trainer.py with config/cifar10, config/cifar100) a
+training step is some 350 launches of 5-20 us each, and the gaps between launches are a fifth of the step.
+`GraphedForwardBackward` captures model(x[, unk_mask]) -> loss -> backward once (every kernel of this package is
+launched on torch's current stream, so torch's stream capture records them) and replays it per step; the
+optimizer runs outside the graph on the gradients the replay leaves in `param.grad`.
+
+Shapes are fixed at capture.  Inputs are copied into static tensors before each replay; `unk_mask`, when the
+model takes one, is a static device tensor refreshed the same way.  Code that decides anything on the host from
+device values cannot be captured; dropout draws its seeds on the host, so a model with dropout > 0 replays the same
+masks every step and is rejected here.
+"""
+import torch
+
+
+class GraphedForwardBackward:
+    def __init__(self, model, loss_fn, example_inputs, example_targets, example_unk_mask=None, warmup=3):
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout) and m.p > 0 and model.training:
+                raise ValueError("a model with dropout > 0 cannot be replayed from a graph (host-drawn seeds)")
+        self.model, self.loss_fn = model, loss_fn
+        self.x = example_inputs.clone()
+        self.y = example_targets.clone()
+        self.unk = example_unk_mask.clone() if example_unk_mask is not None else None
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        side = torch.cuda.Stream(device=self.x.device)
+        side.wait_stream(torch.cuda.current_stream(self.x.device))
+        with torch.cuda.stream(side):                    # warm-up off the default stream: lazy one-time set-up
+            for _ in range(warmup):                      # (LDS attributes, workspaces, compute copies) happens here
+                for p in self.params:
+                    p.grad = None
+                self._run().backward()
+        torch.cuda.current_stream(self.x.device).wait_stream(side)
+        for p in self.params:
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._run()
+            self.loss.backward()
+        self.grads = [p.grad for p in self.params]       # static: every replay rewrites these tensors
+
+    def _run(self):
+        out = self.model(self.x, unk_mask=self.unk) if self.unk is not None else self.model(self.x)
+        return self.loss_fn(out, self.y)
+
+    def __call__(self, inputs, targets, unk_mask=None):
+        """Runs forward + backward on the given batch; returns the (static) loss tensor.  Gradients are in
+        `param.grad` afterwards (overwritten, not accumulated)."""
+        self.x.copy_(inputs, non_blocking=True)
+        self.y.copy_(targets, non_blocking=True)
+        if self.unk is not None:
+            self.unk.copy_(unk_mask, non_blocking=True)
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+        self.graph.replay()
+        return self.loss
