@@ -34,3 +34,23 @@ def test_torch_ddp_wraps_the_module_as_the_trainer_does():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "ddp wrap ok" in out, out[-3000:]
+
+
+def test_data_parallel_wrapper_on_one_device():
+    """nn.DataParallel around the drop-in module (one visible device: the wrapper scatters, calls the module and
+    gathers on cuda:0): same logits and gradients as the bare module."""
+    import torch
+    from visiontransformer_amd import ViT
+    kw = dict(image_size=32, patch_size=4, embed_dim=64, num_classes=10, depth=2, heads=4, mlp_dim=128)
+    torch.manual_seed(0)
+    m = ViT.VIT(**kw).to("cuda:0").train()
+    x = torch.randn(8, 3, 32, 32, device="cuda:0")
+    y = torch.randint(0, 10, (8,), device="cuda:0")
+    torch.nn.functional.cross_entropy(m(x), y).backward()
+    want = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    dp = torch.nn.DataParallel(m, device_ids=[0])
+    out = dp(x)
+    assert torch.equal(out, m(x))
+    torch.nn.functional.cross_entropy(out, y).backward()
+    assert all(torch.equal(p.grad, want[k]) for k, p in m.named_parameters())
