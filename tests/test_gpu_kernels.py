@@ -235,8 +235,12 @@ def test_attention_spiky_scores(ops):
 
 def test_attention_rejects_long_sequences(ops):
     from visiontransformer_amd._lib import VitmiError
-    with pytest.raises(VitmiError, match="256"):
-        ops.attn_fwd(torch.zeros(1, 300, 3 * 64, device=DEV, dtype=torch.bfloat16), 1, 300, 1, 64, False)
+    with pytest.raises(VitmiError, match="not supported"):
+        ops.attn_fwd(torch.zeros(1, 609, 3 * 64, device=DEV, dtype=torch.bfloat16), 1, 609, 1, 64, False)
+    with pytest.raises(VitmiError, match="not supported"):        # beyond 256 tokens only bf16 heads of 64
+        ops.attn_fwd(torch.zeros(1, 300, 3 * 32, device=DEV, dtype=torch.bfloat16), 1, 300, 1, 32, False)
+    with pytest.raises(VitmiError, match="not supported"):
+        ops.attn_fwd(torch.zeros(1, 300, 3 * 64, device=DEV), 1, 300, 1, 64, False)
 
 
 # ------------------------------------------------------------------------------------------ misc
@@ -387,3 +391,25 @@ def test_fused_adam_refreshes_transposed_copies_in_one_launch():
         for p, t in zip(ps[:4], transposed):
             assert ops.compute_copy_t(p, torch.bfloat16) is t                     # refreshed in place, not rebuilt
             assert torch.equal(t, p.detach().t().contiguous().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("N", [257, 384, 400, 577, 608])
+def test_attention_long_sequences_bf16(N):
+    """Sequences of 257..608 tokens (heads of 64, bf16): the whole head still sits in LDS, chunk counts 12 / 16 / 19
+    with the chunks beyond N masked.  Against the fp32 expression of mymodel/ViT.py:98-102 and autograd over it."""
+    from visiontransformer_amd import ops
+    B, H, DH = 2, 3, 64
+    gen = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B, N, 3 * H * DH, generator=gen).to(DEV).bfloat16()
+    do = torch.randn(B, N, H * DH, generator=gen).to(DEV).bfloat16()
+    ref_in = qkv.float().requires_grad_(True)
+    q, k, v = (t.reshape(B, N, H, DH).permute(0, 2, 1, 3) for t in ref_in.split(H * DH, dim=-1))
+    p = torch.softmax((q @ k.transpose(-1, -2)) * DH ** -0.5, dim=-1)
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B, N, H * DH)
+    ref.backward(do.float())
+    o, lse, _ = ops.attn_fwd(qkv, B, N, H, DH, False)
+    assert rel_err(o, ref.detach()) < 2e-2
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, DH)
+    assert rel_err(dqkv, ref_in.grad) < 2e-2
+    with pytest.raises(RuntimeError, match="export"):
+        ops.attn_fwd(qkv, B, N, H, DH, True)

@@ -206,3 +206,23 @@ def test_shipped_config_geometries_against_oracle(geom, dtype):
     torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
     worst = max((rel_err(p.grad, grads_ref[k]), k) for k, p in m.named_parameters())
     assert worst[0] < TOL[dtype], worst
+
+
+def test_577_token_model_against_oracle():
+    """384 x 384 pixels at patch 16 (577 tokens, heads of 64): the long-sequence instantiations of the attention
+    kernels inside the whole model, bf16 against the fp32 oracle."""
+    from visiontransformer_amd import ViT
+    kw = dict(image_size=384, patch_size=16, embed_dim=128, num_classes=10, depth=2, heads=2, mlp_dim=256, dim_head=64)
+    params = vit_oracle.init_params(masked=False, seed=8, **kw)
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 3, 384, 384, generator=gen)
+    y = torch.randint(0, 10, (2,), generator=gen)
+    logits_ref, loss_ref, grads_ref = vit_oracle.loss_and_grads(params, x, y, 2)
+    m = ViT.VIT(**kw)
+    m.load_state_dict(params)
+    m = m.to(DEV).train()
+    logits = m(x.to(DEV))
+    assert rel_err(logits, logits_ref) < TOL[torch.bfloat16]
+    torch.nn.functional.cross_entropy(logits, y.to(DEV)).backward()
+    worst = max((rel_err(p.grad, grads_ref[k]), k) for k, p in m.named_parameters())
+    assert worst[0] < TOL[torch.bfloat16], worst

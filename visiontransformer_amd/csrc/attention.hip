@@ -1,6 +1,6 @@
-// Multi-head self-attention core for ViT sequence lengths (N <= 256 tokens: all keys of one
-// head fit in LDS, so the softmax is a single exact pass over the whole row -- the online
-// rescale of a streaming flash kernel never triggers at these lengths).
+// Multi-head self-attention core for ViT sequence lengths (N <= 256 tokens, and up to 608 for bf16 heads of 64:
+// all keys of one head fit in LDS and the scores of a query row fit in registers, so the softmax is a single exact
+// pass over the whole row -- the online rescale of a streaming flash kernel never triggers at these lengths).
 //
 // bf16 kernels (v_mfma_f32_16x16x32_bf16), one workgroup per (image, head):
 //   forward : K and V^T of the head are staged once in LDS.  A wave owns 16 query rows and
@@ -143,7 +143,7 @@ __host__ __device__ __forceinline__ int export_tile_elems(int N) { return (16 * 
 // values that feed P V.  Chunks of 32 keys that lie wholly beyond N are skipped, only the chunk
 // that straddles N pays for the key mask; exponentials are raw v_exp_f32.
 template <int DH, int NC, bool EXPORT, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8 ? 4 : (NC <= 16 ? 2 : 1), NC <= 8 ? 4 : (NC <= 16 ? 2 : 1)))) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, bf16_t* __restrict__ probs, int N,
                                                             int H, float scale) {
     using A = AttnDims<DH>;
@@ -691,7 +691,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_f32_kernel(const float* __res
 // ---------------------------------------------------------------- dispatch helpers
 inline int pick_nc(int N) {
     const int need = (N + 31) / 32;
-    const int avail[] = {1, 2, 3, 4, 5, 6, 7, 8};
+    // 1..8 exact (every chunk holds a real key); 12, 16, 19 chunks for sequences up to 608 tokens, where the whole
+    // head still fits in LDS (one workgroup per CU) and chunks that lie beyond N are masked like the straddling one
+    const int avail[] = {1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 19};
     for (int a : avail)
         if (need <= a) return a;
     return 0;
@@ -756,6 +758,12 @@ int launch_fwd_x(const void* qkv, void* out, float* lse, void* probs, int B, int
 }
 
 template <int DH, int NC>
+int launch_fwd_noexport(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t s) {
+    // the score tile of all keys lives in registers: 19 chunks need the 512 registers of a lone wave per SIMD
+    return launch_fwd_t<DH, NC, false, (NC > 16 ? ATTN_THREADS / 2 : ATTN_THREADS)>(qkv, out, lse, nullptr, B, N, H, s);
+}
+
+template <int DH, int NC>
 int launch_fwd(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
     if (probs) return launch_fwd_x<DH, NC, true>(qkv, out, lse, probs, B, N, H, s);
     return launch_fwd_x<DH, NC, false>(qkv, out, lse, probs, B, N, H, s);
@@ -791,6 +799,13 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
         case 7: return FN<DH, 7>(__VA_ARGS__);        \
         default: return FN<DH, 8>(__VA_ARGS__);       \
     }
+// sequences of 257..608 tokens: head dim 64 only
+#define DISPATCH_NC_LONG(FN, ...)                     \
+    switch (nc) {                                     \
+        case 12: return FN<64, 12>(__VA_ARGS__);      \
+        case 16: return FN<64, 16>(__VA_ARGS__);      \
+        default: return FN<64, 19>(__VA_ARGS__);      \
+    }
 
 inline size_t f32_fwd_smem(int N, int DH) { return ((size_t)2 * N * (DH + 1) + 4 * DH + 4 * N) * sizeof(float); }
 inline size_t f32_bwdq_smem(int N, int DH) { return ((size_t)2 * N * (DH + 1) + 8 * DH + 4 * N) * sizeof(float); }
@@ -799,8 +814,9 @@ inline size_t f32_bwdkv_smem(int N, int DH) { return ((size_t)2 * N * (DH + 1)) 
 int check_common(const char* who, int dt, int B, int N, int H, int DH) {
     VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "%s: bad dtype %d", who, dt);
     VITMI_CHECK_ARG(B > 0 && N > 0 && H > 0 && DH > 0, "%s: bad shape B=%d N=%d H=%d DH=%d", who, B, N, H, DH);
-    if (N > 256) {
-        vitmi_set_error("%s: sequence length N=%d exceeds the supported 256 tokens", who, N);
+    if (N > 608 || (N > 256 && !(dt == VITMI_BF16 && DH == 64))) {
+        vitmi_set_error("%s: sequence length N=%d is not supported (up to 256 tokens; up to 608 for bf16 heads of 64)", who,
+                        N);
         return VITMI_ERR_UNSUPPORTED;
     }
     if (dt == VITMI_BF16 && !(DH == 8 || DH == 16 || DH == 32 || DH == 64)) {
@@ -835,6 +851,13 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* prob
         return VITMI_OK;
     }
     const int nc = pick_nc(N);
+    if (nc > 8) {
+        if (probs) {
+            vitmi_set_error("vitmi_attn_fwd: the probability export is limited to 256 tokens (N=%d)", N);
+            return VITMI_ERR_UNSUPPORTED;
+        }
+        DISPATCH_NC_LONG(launch_fwd_noexport, qkv, out, lse, B, N, H, s)
+    }
     switch (DH) {
         case 8: DISPATCH_NC(launch_fwd, 8, qkv, out, lse, probs, B, N, H, s)
         case 16: DISPATCH_NC(launch_fwd, 16, qkv, out, lse, probs, B, N, H, s)
@@ -882,6 +905,7 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
         return VITMI_OK;
     }
     const int nc = pick_nc(N);
+    if (nc > 8) DISPATCH_NC_LONG(launch_bwd, qkv, out, dout, lse, dqkv, B, N, H, s)
     switch (DH) {
         case 8: DISPATCH_NC(launch_bwd, 8, qkv, out, dout, lse, dqkv, B, N, H, s)
         case 16: DISPATCH_NC(launch_bwd, 16, qkv, out, dout, lse, dqkv, B, N, H, s)
