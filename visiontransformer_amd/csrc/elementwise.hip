@@ -250,53 +250,78 @@ __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long 
 // ITERS = ceil(D / (64*V)) is a template parameter so the per-lane row slice stays in registers.
 
 template <typename T, int V, int LN_MAX_ITERS>
-__global__ void layernorm_fwd_kernel(const T* __restrict__ x, long long ldx, const float* __restrict__ gamma,
-                                     const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mean,
-                                     float* __restrict__ rstd, long long rows, int D, float eps) {
-    const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const T* xr = x + row * ldx;
-    float v[LN_MAX_ITERS][V];
-    float s = 0.f;
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, long long ldx,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            float* __restrict__ mean, float* __restrict__ rstd,
+                                                            long long rows, int D, float eps) {
+    // a wave walks rows (grid-strided) one row ahead: the next row's load is in flight while the current row is
+    // reduced, normalised and stored; gamma and beta stay in registers across rows
+    typedef Vec<T, V> __attribute__((aligned(sizeof(T) * V))) VT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const long long stride = (long long)gridDim.x * nw;
+    float g[LN_MAX_ITERS][V], bt[LN_MAX_ITERS][V];
 #pragma unroll
     for (int it = 0; it < LN_MAX_ITERS; ++it) {
         const int c = (it * 64 + lane) * V;
-        if (c < D) {
-            load_vec<T, V>(xr + c, v[it]);
 #pragma unroll
-            for (int j = 0; j < V; ++j) s += v[it][j];
+        for (int j = 0; j < V; ++j) g[it][j] = bt[it][j] = 0.f;
+        if (c < D) {
+            load_vec<float, V>(gamma + c, g[it]);
+            load_vec<float, V>(beta + c, bt[it]);
         }
     }
-    const float mu = wave_sum(s) / (float)D;
-    float q = 0.f;
+    VT nx[LN_MAX_ITERS];
+    auto fetch = [&](long long row) {
 #pragma unroll
-    for (int it = 0; it < LN_MAX_ITERS; ++it) {
-        const int c = (it * 64 + lane) * V;
-        if (c < D) {
+        for (int it = 0; it < LN_MAX_ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
+            if (c < D) nx[it] = *reinterpret_cast<const VT*>(x + row * ldx + c);
+        }
+    };
+    long long row = (long long)blockIdx.x * nw + wave;
+    if (row < rows) fetch(row);
+    for (; row < rows; row += stride) {
+        float v[LN_MAX_ITERS][V];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < LN_MAX_ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const float d = v[it][j] - mu;
-                q += d * d;
+                v[it][j] = c < D ? to_f32(nx[it].v[j]) : 0.f;
+                s += v[it][j];
             }
         }
-    }
-    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
-    if (lane == 0) {
-        if (mean) mean[row] = mu;
-        if (rstd) rstd[row] = rs;
-    }
-    T* yr = y + row * (long long)D;
+        if (row + stride < rows) fetch(row + stride);
+        const float mu = wave_sum(s) / (float)D;
+        float q = 0.f;
 #pragma unroll
-    for (int it = 0; it < LN_MAX_ITERS; ++it) {
-        const int c = (it * 64 + lane) * V;
-        if (c < D) {
-            float g[V], bt[V], o[V];
-            load_vec<float, V>(gamma + c, g);
-            load_vec<float, V>(beta + c, bt);
+        for (int it = 0; it < LN_MAX_ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
+            if (c < D) {
 #pragma unroll
-            for (int j = 0; j < V; ++j) o[j] = (v[it][j] - mu) * rs * g[j] + bt[j];
-            store_vec<T, V>(yr + c, o);
+                for (int j = 0; j < V; ++j) {
+                    const float d = v[it][j] - mu;
+                    q += d * d;
+                }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+        if (lane == 0) {
+            if (mean) mean[row] = mu;
+            if (rstd) rstd[row] = rs;
+        }
+        T* yr = y + row * (long long)D;
+#pragma unroll
+        for (int it = 0; it < LN_MAX_ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
+            if (c < D) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) o[j] = (v[it][j] - mu) * rs * g[it][j] + bt[it][j];
+                store_vec<T, V>(yr + c, o);
+            }
         }
     }
 }
@@ -876,7 +901,8 @@ extern "C" int vitmi_layernorm_fwd(const void* x, long long ldx, const float* ga
         vitmi_set_error("vitmi_layernorm_fwd: bad dtype %d", dt);
         return VITMI_ERR_BAD_ARG;
     }
-    dim3 grid(ceil_div(rows, 4)), block(256);
+    // four 4-wave blocks per CU on 256 CUs, every wave walking rows with the next row's load outstanding
+    dim3 grid((unsigned)std::min<long long>(ceil_div(rows, 4), 1024)), block(256);
 #define LN_FWD(T, V, I)                                                                                         \
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, V, I>), grid, block, 0, s, (const T*)x, ldx, gamma, beta, (T*)y, \
                        mean, rstd, rows, D, eps)
