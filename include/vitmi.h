@@ -318,8 +318,8 @@ int vitmi_adam_step_multi(const vitmi_adam_tensor* tensors, int n_tensors, const
                           float weight_decay, int step, float grad_scale, void* stream);
 
 /* vitmi_transpose_cast (fp32 source) for many matrices in ONE launch: job j writes dst[c][r] = (bf16) src[r][c]
- * for its rows x cols matrix.  jobs and tile_start live on the device; tile_start[j] = number of 32 x 32 tiles
- * of the jobs before j (ceil(rows/32) * ceil(cols/32) each), total_tiles their sum = the grid.  Used after the
+ * for its rows x cols matrix.  jobs and tile_start live on the device; tile_start[j] = number of 64 x 64 tiles
+ * of the jobs before j (ceil(rows/64) * ceil(cols/64) each), total_tiles their sum = the grid.  Used after the
  * optimizer step to refresh every transposed weight copy at once (49 launches per step for ViT-B/16 otherwise). */
 typedef struct {
     const void* src;

@@ -535,10 +535,12 @@ __global__ void patchify_kernel(const S* __restrict__ x, T* __restrict__ out, in
 
 // ---------------------------------------------------------------- transposed bf16 copies of many fp32 matrices
 // dst[c][r] = (bf16) src[r][c] for every job in one launch: block t finds its job by bisection over the
-// prefix of 32x32-tile counts, then moves one tile through LDS (reads and writes both in runs along a row).
+// prefix of 64x64-tile counts, then moves one tile through LDS: 256-byte runs of the fp32 rows in, 128-byte runs of
+// the bf16 rows out.
+constexpr int TT = 64;
 __global__ __launch_bounds__(256) void transpose_cast_multi_kernel(const vitmi_transpose_job* __restrict__ jobs,
                                                                   const long long* __restrict__ tile_start, int n_jobs) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[TT][TT + 1];
     const long long t = blockIdx.x;
     int lo = 0, hi = n_jobs - 1;
     while (lo < hi) {                   // last job whose first tile is <= t
@@ -550,16 +552,18 @@ __global__ __launch_bounds__(256) void transpose_cast_multi_kernel(const vitmi_t
     const float* in = reinterpret_cast<const float*>(job.src);
     bf16_t* out = reinterpret_cast<bf16_t*>(job.dst);
     const int R = (int)job.rows, Cn = (int)job.cols;
-    const int tiles_c = (Cn + 31) >> 5;
+    const int tiles_c = (Cn + TT - 1) / TT;
     const int local = (int)(t - tile_start[lo]);
-    const int c0 = (local % tiles_c) * 32, r0 = (local / tiles_c) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int k = ty; k < 32; k += 8) {
+    const int c0 = (local % tiles_c) * TT, r0 = (local / tiles_c) * TT;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+#pragma unroll 4
+    for (int k = ty; k < TT; k += 4) {
         const int r = r0 + k, c = c0 + tx;
         tile[k][tx] = (r < R && c < Cn) ? in[(long long)r * Cn + c] : 0.f;
     }
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
+#pragma unroll 4
+    for (int k = ty; k < TT; k += 4) {
         const int c = c0 + k, r = r0 + tx;
         if (c < Cn && r < R) out[(long long)c * R + r] = (bf16_t)tile[tx][k];
     }

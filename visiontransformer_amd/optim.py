@@ -96,7 +96,7 @@ class FusedAdam:
                                                 self.eps, self.weight_decay, self.step_count, grad_scale,
                                                 ops._stream()), "vitmi_adam_step_multi")
                 if jobs:
-                    tiles = [((r + 31) // 32) * ((c + 31) // 32) for _, _, r, c in jobs]
+                    tiles = [((r + 63) // 64) * ((c + 63) // 64) for _, _, r, c in jobs]
                     starts = np.concatenate([[0], np.cumsum(tiles)[:-1]]).astype(np.int64)
                     table = ops.upload(np.concatenate([np.asarray(jobs, dtype=np.int64).reshape(-1), starts]), device)
                     check(lib.vitmi_transpose_cast_multi(table.data_ptr(), table.data_ptr() + 32 * len(jobs), len(jobs),
