@@ -37,6 +37,10 @@ WORKLOADS = {
     "cifar_mask_pbf": (dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=12, heads=12,
                             mlp_dim=512), "pbf", 256, 1.327),
     # the timm-style ViT-S/16 with unk_mask that trainer.py:172-176 builds (dim_head = 384/6 = 64, mlp 1536)
+    # BASELINE config 5: DP-SGD (defence_method/DPSGD.py:111-136) with per-sample clipping, as one batched forward, a
+    # per-sample-norm backward and a clipped backward; clip 1.0, noise multiplier 1.0 (DPSGD.py:26,31)
+    "dpsgd_vit_b16": (dict(image_size=224, patch_size=16, embed_dim=768, num_classes=100, depth=12, heads=12,
+                           mlp_dim=3072, dim_head=64), "dpsgd", 256, 105.378822144),
     "tim_vit_small_mask": (dict(image_size=224, patch_size=16, embed_dim=384, num_classes=100, depth=12, heads=6,
                                 mlp_dim=1536, dim_head=64), "timm", 256, 27.59),
 }
@@ -145,7 +149,7 @@ def main():
         model = VisionTransformer(img_size=kw["image_size"], patch_size=kw["patch_size"], num_classes=kw["num_classes"],
                                   embed_dim=kw["embed_dim"], depth=kw["depth"], num_heads=kw["heads"]).to(dev)
     else:
-        model = (ViT_mask if masked else ViT).VIT(**kw).to(dev)
+        model = (ViT_mask if masked and masked != "dpsgd" else ViT).VIT(**kw).to(dev)
     if masked in (True, "pbf"):
         model.train_method = "mask"
     model.train()
@@ -159,6 +163,11 @@ def main():
     x = torch.randn(batch, 3, kw["image_size"], kw["image_size"], device=dev)
     y = torch.randint(0, kw["num_classes"], (batch,), device=dev)
     unk = None
+    dp_gen = None
+    if masked == "dpsgd":
+        from visiontransformer_amd import dpsgd
+        dp_gen = torch.Generator(device=dev).manual_seed(4321)      # same state on every rank: one noise draw
+        masked = False
     if masked:
         import random
         import numpy as np
@@ -172,8 +181,15 @@ def main():
         jigsaw = JigsawPuzzleMaskedRegion(kw["image_size"], kw["patch_size"], grid * grid // 2, 4, mask_type="pbf",
                                           device=dev, pub_data=bank)
 
+    def dpsgd_step(i):
+        loss, _ = dpsgd.clipped_noised_gradients(model, x, y, 1.0, 1.0, generator=dp_gen, reducer=reducer)
+        opt.step()
+        return loss
+
     def step(i):
         nonlocal unk
+        if dp_gen is not None:
+            return dpsgd_step(i)
         xin = x
         if masked:
             random.seed(1234 + i), np.random.seed(1234 + i)

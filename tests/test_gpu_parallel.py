@@ -54,3 +54,15 @@ def test_data_parallel_wrapper_on_one_device():
     assert torch.equal(out, m(x))
     torch.nn.functional.cross_entropy(out, y).backward()
     assert all(torch.equal(p.grad, want[k]) for k, p in m.named_parameters())
+
+
+def test_dpsgd_through_the_reducer_on_rccl():
+    """Batched DP-SGD with the gradient reducer (sum over ranks, one noise draw, division by the global batch): one
+    rank on RCCL gives bit for bit the gradient of the step without a reducer."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-u", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tools", "dpsgd_dist_check.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "dpsgd dist ok" in out, out[-3000:]
+    assert "with / without the reducer on one rank: 0.000e+00" in out

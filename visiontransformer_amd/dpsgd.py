@@ -39,9 +39,14 @@ def per_sample_grad_norms(model, losses):
 
 
 def clipped_noised_gradients(model, inputs, labels, l2_norm_clip=1.0, noise_multiplier=1.0, generator=None,
-                             loss_fn=per_sample_losses, **forward_kwargs):
+                             loss_fn=per_sample_losses, reducer=None, **forward_kwargs):
     """Leaves (sum_i clip(g_i) + N(0, (noise_multiplier * l2_norm_clip)^2)) / B in every parameter's .grad
-    (DPSGD.py:122-127) and returns (mean loss, per-sample norms)."""
+    (DPSGD.py:122-127) and returns (mean loss, per-sample norms).
+
+    Data parallel: pass the rank's `parallel.GradReducer(model, average=False)` as `reducer`.  The clipped sums of
+    all ranks are then added (the bucketed all-reduce runs under the second backward pass), ONE noise draw is added
+    to the global sum and the result is divided by the global batch; every rank must hand in a generator in the same
+    state so that the replicas add the same noise and stay identical."""
     B = inputs.shape[0]
     logits = model(inputs, **forward_kwargs)
     losses = loss_fn(logits, labels)
@@ -52,15 +57,21 @@ def clipped_noised_gradients(model, inputs, labels, l2_norm_clip=1.0, noise_mult
     for p in model.parameters():
         p.grad = None
     (losses * coef).sum().backward()
+    total = B
+    if reducer is not None:
+        if reducer.average:
+            raise ValueError("the reducer must sum (average=False): the division by the global batch happens here")
+        reducer.finish()
+        total = B * reducer.world
     std = noise_multiplier * l2_norm_clip
     for p in model.parameters():
         if p.grad is None:
             continue
         if std > 0:
             noise = torch.empty_like(p.grad).normal_(0, std, generator=generator)
-            p.grad = (p.grad + noise) / B
+            p.grad = (p.grad + noise) / total
         else:
-            p.grad = p.grad / B
+            p.grad = p.grad / total
     return losses.detach().mean(), norms
 
 

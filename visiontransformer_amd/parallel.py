@@ -80,6 +80,8 @@ class GradReducer:
         self.buckets.append(b)
 
     def _on_grad(self, p):
+        if p.grad is None:      # the accumulation node ran with an undefined gradient (a backward pass that hands
+            return              # this parameter nothing, e.g. the per-sample-norm pass of DP-SGD): not an arrival
         b, i = self._slot[p]
         if p in self._seen:  # second accumulation into the same gradient in one backward
             raise RuntimeError("GradReducer: a parameter received two gradients before finish()")
