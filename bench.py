@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak of one MI355X (vendor spec, no sparsity)
 HBM_PEAK_GBS = 8000.0
+PROF_STRIDE = 5                # launch timers sample every 5th launch of the reported family
 
 WORKLOADS = {
     # name: (ctor args, masked?, per-GPU batch, classes, train GFLOP/img = 6 * fwd MACs)
@@ -109,6 +110,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay forward + loss + backward from one HIP graph (one GPU; implies --no-kernel-timers: "
+                         "event records cannot be captured, so the line carries no roofline)")
     args = ap.parse_args()
 
     if os.environ.get("VITMI_BENCH_WATCHDOG"):      # dump every thread's stack if the run stalls
@@ -186,6 +190,8 @@ def main():
         opt.step()
         return loss
 
+    graphed = None
+
     def step(i):
         nonlocal unk
         if dp_gen is not None:
@@ -198,6 +204,10 @@ def main():
             else:
                 um = MaskingGenerator.unk_mask_from_flat(gen.masked_indexes()[0])
             unk = ops.upload(um.astype(np.int64), dev)      # pinned staging: the host does not wait for the stream
+        if graphed is not None:
+            loss = graphed(xin, y, unk)
+            opt.step()
+            return loss
         opt.zero_grad(set_to_none=True)
         logits = model(xin, unk_mask=unk) if masked else model(xin)
         loss = torch.nn.functional.cross_entropy(logits, y)
@@ -215,7 +225,13 @@ def main():
     # Kernel timers (two HIP event records per launch) cost GPU time themselves: every family is timed over the
     # last warm-up steps, which yields the per-family shares and names the dominant family; inside the timed
     # region only that family is timed, on every one of its launches.
-    timers = not args.no_kernel_timers
+    if args.graph:
+        if world > 1 or dp_gen is not None:
+            raise SystemExit("--graph: one GPU, and not the DP-SGD workload")
+        from visiontransformer_amd.graphs import GraphedForwardBackward
+        step(0)                                          # one eager step: lazy set-up, and a mask to size the capture
+        graphed = GraphedForwardBackward(model, torch.nn.functional.cross_entropy, x, y, unk)
+    timers = not (args.no_kernel_timers or args.graph)
     survey_steps = min(args.warmup, 2) if timers else 0
     for i in range(args.warmup - survey_steps):
         step(i)
@@ -239,6 +255,9 @@ def main():
     if timers and dominant >= 0:
         _lib.check(_lib.lib.vitmi_prof_reset())
         _lib.check(_lib.lib.vitmi_prof_select(dominant))
+        # every 5th launch of the family (5 is coprime to the 6 shapes x 12 layers of its launch sequence, so every
+        # shape is sampled equally over the steps): timing all of them costs 3 % of the step in event records
+        _lib.check(_lib.lib.vitmi_prof_stride(PROF_STRIDE))
         _lib.check(_lib.lib.vitmi_prof_enable(1))
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -248,6 +267,7 @@ def main():
     if timers:
         _lib.check(_lib.lib.vitmi_prof_enable(0))
         _lib.check(_lib.lib.vitmi_prof_select(-1))
+        _lib.check(_lib.lib.vitmi_prof_stride(1))
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -267,7 +287,7 @@ def main():
             roof = {"bound": "mfma" if is_flop else "hbm", "achieved": achieved, "peak": peak,
                     "unit": "TFLOP/s" if is_flop else "GB/s", "frac": achieved / peak, "traffic": None,
                     "kernel": name, "launches": n, "avg_launch_ms": ms / n,
-                    "timed": f"every launch of this family inside the timed region ({args.steps} steps)",
+                    "timed": f"every {PROF_STRIDE}th launch of this family inside the timed region ({args.steps} steps)",
                     "time_share_ms_per_step": {_lib.lib.vitmi_prof_name(f).decode(): round(m, 3) for m, f in shares},
                     "time_share_from": f"all families timed over the last {survey_steps} warm-up steps"}
         if roof is not None and args.workload == "vit_b16_224" and batch == 256:
@@ -286,6 +306,7 @@ def main():
                                    "(fp32 master weights), N(0,1) images resident in HBM",
                        "global_batch": batch * world, "seq_len": (kw["image_size"] // kw["patch_size"]) ** 2 + 1,
                        "parallelism": f"dp{world}"},
+            "graph": bool(args.graph),
             "train_gflop_per_image": gflop_img,
             "step_mfma_frac_per_gpu": step_tflops / MFMA_PEAK_TFLOPS,
             "final_loss": loss_val,

@@ -69,6 +69,9 @@ int vitmi_prof_reset(void);
  * every family timed a ViT-B/16 step runs 3 % slower and a 32x32-pixel step 25 % slower, so a benchmark times
  * everything during warm-up and only the kernel it reports on inside its timed region. */
 int vitmi_prof_select(int family);
+/* Time every `every`-th launch of the timed families (default 1 = all): the averages stay per launch, the GPU time
+ * spent on event records drops by the same factor.  Pick a stride coprime to the period of the launch sequence. */
+int vitmi_prof_stride(int every);
 int vitmi_prof_read(int family, double* total_ms, double* total_work, long long* launches);
 const char* vitmi_prof_name(int family);
 

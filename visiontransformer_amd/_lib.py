@@ -25,6 +25,7 @@ SIGNATURES = {
     "vitmi_prof_enable": (I, [I]),
     "vitmi_prof_reset": (I, []),
     "vitmi_prof_select": (I, [I]),
+    "vitmi_prof_stride": (I, [I]),
     "vitmi_prof_read": (I, [I, ctypes.POINTER(c_double), ctypes.POINTER(c_double), ctypes.POINTER(c_longlong)]),
     "vitmi_prof_name": (c_char_p, [I]),
     "vitmi_cast": (I, [P, I, P, I, L, P]),

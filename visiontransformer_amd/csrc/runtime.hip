@@ -41,6 +41,8 @@ struct Family {
 std::mutex g_mu;
 bool g_on = false;
 int g_only = -1;  // >= 0: only this family is timed
+int g_stride = 1;  // every g_stride-th launch of a timed family carries events
+long long g_seen[VITMI_FAM_COUNT] = {0};
 Family g_fam[VITMI_FAM_COUNT];
 std::vector<hipEvent_t> g_pool;  // recycled events: creating one per launch would cost more than recording it
 
@@ -60,6 +62,7 @@ void vitmi_prof_record_begin(int family, hipStream_t s, double work) {
     if (!g_on || (g_only >= 0 && family != g_only)) return;
     std::lock_guard<std::mutex> lk(g_mu);
     Family& f = g_fam[family];
+    if (g_seen[family]++ % g_stride != 0) return;
     hipEvent_t a = take_event();
     if (!a) return;
     (void)hipEventRecord(a, s);
@@ -92,6 +95,13 @@ extern "C" int vitmi_prof_select(int family) {
     return VITMI_OK;
 }
 
+extern "C" int vitmi_prof_stride(int every) {
+    VITMI_CHECK_ARG(every >= 1, "vitmi_prof_stride: stride %d < 1", every);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_stride = every;
+    return VITMI_OK;
+}
+
 extern "C" int vitmi_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& f : g_fam) {
@@ -103,6 +113,7 @@ extern "C" int vitmi_prof_reset(void) {
         if (f.pending) g_pool.push_back(f.pending);
         f.pending = nullptr;
     }
+    for (auto& n : g_seen) n = 0;
     return VITMI_OK;
 }
 
