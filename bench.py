@@ -136,7 +136,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VITMI_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # the collectives' kernels go on a high-priority stream: the GEMMs keep every CU full (one 512-thread
+            # workgroup with the whole register file per CU), so an all-reduce only advances when a CU frees up
+            opts = None
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                pass
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
