@@ -67,3 +67,54 @@ def test_bucketed_allreduce_equals_single_process_large_batch():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok
+
+
+class _NoWeightGrad(torch.autograd.Function):
+    """y = x * w whose backward hands the weight nothing (what the per-sample-norm pass of DP-SGD does)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(w)
+        return x * w
+
+    @staticmethod
+    def backward(ctx, g):
+        (w,) = ctx.saved_tensors
+        return g * w, None
+
+
+def _worker_undefined(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from visiontransformer_amd.parallel import GradReducer
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(4, 4)
+    w = torch.nn.Parameter(torch.ones(4))
+    model = torch.nn.ParameterList([w, *lin.parameters()])
+    red = GradReducer(model, bucket_mb=0.00001, average=False)
+    x = torch.full((2, 4), float(rank + 1))
+    # a backward pass in which w's accumulation node runs with an undefined gradient: no arrival, no collective
+    _NoWeightGrad.apply(x.clone().requires_grad_(True), w).sum().backward()
+    assert w.grad is None and all(b.work is None for b in red.buckets)
+    # the real pass: every parameter arrives, sums over the two ranks
+    (lin(x) * w).sum().backward()
+    red.finish()
+    ok = torch.allclose(w.grad, sum(lin(torch.full((2, 4), float(r + 1))).sum(0) for r in range(world)).detach())
+    if rank == 0:
+        out.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_ignores_undefined_gradient_arrivals():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_undefined, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) is True
