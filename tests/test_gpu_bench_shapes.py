@@ -1,0 +1,128 @@
+"""GPU parity at the shapes bench.py runs: ViT-B/16 224 px at batch 256 has M = 256 * 197 = 50432 token rows, and
+every encoder GEMM of that step has at least 256 output tiles of 256 x 256, so `pick_nt_cfg` sends it to the
+persistent `gemm_nt_phased_kernel` (K % 64 == 0: 12, 36 or 48 K-tiles, 48-192 streamed regions, every block
+walking 2-10 tiles) and every weight gradient to `gemm_tn_phased_kernel` + slab reduction.  The small-shape tests
+in test_gpu_kernels.py reach those kernels with at most three K-tiles; here they run at depth.
+
+Reference: the fp32 CPU product of the bf16-rounded operands (every output element, not a sample), with the
+epilogue evaluated by the oracle's fp32 expressions (mymodel/ViT.py:66-70, 86-89, 119-120).  Bar: 1e-2 relative
+(max|a-b| / max|b|), tighter than the 2e-2 bf16 bar of the model tests; fp32 weight gradients 1e-4.
+The whole-model case runs one ViT-B/16 block at batch 128 (25216 rows, ragged last m-tile, 297-1188 tiles per GEMM:
+the same kernels) against `vit_oracle.loss_and_grads` on the CPU.
+"""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import vit_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+M_BENCH = 256 * 197
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t):
+    return t.to(BF).float()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from visiontransformer_amd import ops as o
+    return o
+
+
+# (N, K) of the five distinct nt products of a ViT-B/16 block: qkv, out projection, fc2, dX of qkv, fc1;
+# the ragged M leaves 100 rows of the last 256-row tile empty
+@pytest.mark.parametrize("M,N,K", [(M_BENCH, 2304, 768), (M_BENCH, 768, 768), (M_BENCH, 768, 3072),
+                                   (M_BENCH, 768, 2304), (M_BENCH, 3072, 768), (M_BENCH - 100, 768, 768),
+                                   (M_BENCH - 100, 3072, 768)])
+def test_phased_nt_gemm_forward_epilogues_at_bench_shapes(ops, M, N, K):
+    """linear_fwd -> gemm_nt_phased_kernel<NONE,bf16> (plain, bias + residual), <GELU,bf16> (bias, pre-activation
+    written out) and <NONE,f32>."""
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    xd, wd, bd = x.to(DEV, BF), w.to(DEV, BF), b.to(DEV)
+    pre = q(x) @ q(w).t()
+    y, _ = ops.linear_fwd(xd, wd)
+    assert rel_err(y, pre) < 1e-2
+    res = rnd(M, N, seed=4)
+    y, _ = ops.linear_fwd(xd, wd, bd, res=res.to(DEV, BF))
+    assert rel_err(y, pre + b + q(res)) < 1e-2
+    del res
+    if N == 3072:                                       # the first MLP layer is the only GELU product of the step
+        h, u = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_GELU, want_aux=True)
+        assert rel_err(u, pre + b) < 1e-2
+        assert rel_err(h, vit_oracle.gelu_erf(pre + b)) < 1e-2
+    if N == 768 and K == 768:
+        y32, _ = ops.linear_fwd(xd, wd, bd, out_dtype=torch.float32)
+        assert rel_err(y32, pre + b) < 2e-3
+
+
+# (rows, width of dy, width of dx): dX of fc2 (into the dGELU epilogue), of fc1, of qkv, of the out projection
+@pytest.mark.parametrize("M,N,K", [(M_BENCH, 768, 3072), (M_BENCH, 3072, 768), (M_BENCH, 2304, 768),
+                                   (M_BENCH - 100, 768, 3072)])
+def test_phased_nt_gemm_input_gradients_at_bench_shapes(ops, M, N, K):
+    """linear_bwd_x through the transposed weight copy -> gemm_nt_phased_kernel<NONE,bf16>; with K = 3072 also
+    <DGELU,bf16,false> and the fused column-sum variant <DGELU,bf16,true> (bias gradient of the first MLP layer)."""
+    dy, w = rnd(M, N, seed=5), rnd(N, K, seed=6, scale=N ** -0.5)
+    dyd = dy.to(DEV, BF)
+    wp = torch.nn.Parameter(w.to(DEV))
+    wd, wt = ops.compute_copy(wp, BF), ops.compute_copy_t(wp, BF)
+    ref = q(dy) @ q(w)
+    dx = ops.linear_bwd_x(dyd, wd, w_t=wt)
+    assert rel_err(dx, ref) < 1e-2
+    if K != 3072:
+        return
+    aux = rnd(M, K, seed=7)
+    auxd = aux.to(DEV, BF)
+    a = q(aux).requires_grad_(True)
+    vit_oracle.gelu_erf(a).backward(ref)
+    du = ops.linear_bwd_x(dyd, wd, epi=ops.EPI_DGELU, aux=auxd, w_t=wt)
+    assert rel_err(du, a.grad) < 1e-2
+    du2, cs = ops.linear_bwd_x(dyd, wd, epi=ops.EPI_DGELU, aux=auxd, w_t=wt, want_colsum=True)
+    assert torch.equal(du2, du)
+    assert rel_err(cs, a.grad.double().sum(0)) < 1e-2
+    assert rel_err(cs, du.double().sum(0)) < 2e-3          # sums of the unrounded values vs sums of their bf16
+
+
+@pytest.mark.parametrize("T,P,Q", [(M_BENCH, 2304, 768), (M_BENCH, 768, 768), (M_BENCH, 3072, 768),
+                                   (M_BENCH, 768, 3072)])
+def test_phased_weight_gradient_gemm_at_bench_shapes(ops, T, P, Q):
+    """linear_bwd_w -> gemm_tn_phased_kernel over 788 token tiles, split into one round of slabs."""
+    dy, x = rnd(T, P, seed=8), rnd(T, Q, seed=9)
+    dw = ops.linear_bwd_w(dy.to(DEV, BF), x.to(DEV, BF))
+    ref = q(dy).double().t() @ q(x).double()
+    assert rel_err(dw, ref) < 1e-4
+    assert torch.equal(dw, ops.linear_bwd_w(dy.to(DEV, BF), x.to(DEV, BF)))
+
+
+def test_vit_b16_block_at_batch_128_against_oracle():
+    """One ViT-B/16 encoder block (mymodel/ViT.py:93-121 with D 768, H 12, dh 64, mlp 3072) at batch 128, bf16:
+    25216 token rows, so qkv / out / fc1 / fc2 and their input gradients have 297-1188 output tiles and run on
+    gemm_nt_phased_kernel (all epilogues), the four weight gradients on gemm_tn_phased_kernel, attention on the
+    13-tile N = 197 instantiations -- the kernels of the benchmark step.  Logits, loss and every gradient against
+    the CPU oracle, 2e-2 relative."""
+    from visiontransformer_amd import ViT
+    kw = dict(image_size=224, patch_size=16, embed_dim=768, num_classes=100, depth=1, heads=12, mlp_dim=3072,
+              dim_head=64)
+    params = vit_oracle.init_params(masked=False, seed=5, **kw)
+    g = torch.Generator().manual_seed(17)
+    B = 128
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, 100, (B,), generator=g)
+    logits_ref, loss_ref, grads_ref = vit_oracle.loss_and_grads(params, x, y, 12)
+    m = ViT.VIT(**kw)
+    m.load_state_dict(params)
+    m = m.to(DEV).set_compute_dtype(BF).train()
+    logits = m(x.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(DEV))
+    loss.backward()
+    assert rel_err(logits, logits_ref) < 2e-2
+    assert abs(loss.item() - loss_ref.item()) < 2e-2 * max(1.0, abs(loss_ref.item()))
+    worst = max((rel_err(p.grad, grads_ref[k]), k) for k, p in m.named_parameters())
+    assert worst[0] < 2e-2, worst
