@@ -215,6 +215,18 @@ int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx, const floa
                         const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
                         float* dres_colsum, void* workspace, int dt, long long rows, int D, void* stream);
 
+/* vitmi_layernorm_bwd without a workspace argument, for callers that cannot allocate (code under HIP graph
+ * capture, tight serving / fine-tuning loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * The per-block partial sums live in a device array of the library (768 * 3 * VITMI_LN_BWD_STATIC_MAX_D floats =
+ * 9 MiB per GPU, held until the process ends); the call allocates and frees nothing.  D above
+ * VITMI_LN_BWD_STATIC_MAX_D returns VITMI_ERR_UNSUPPORTED.  Same arguments, kernels and results (bit for bit) as
+ * vitmi_layernorm_bwd.  All calls on one GPU share the array: calls that overlap on one GPU (two streams) race;
+ * nothing in it has to be zero between calls.  The device current at the call must be the stream's device. */
+#define VITMI_LN_BWD_STATIC_MAX_D 1024
+int vitmi_layernorm_bwd_static(const void* dy, const void* x, long long ldx, const float* gamma, const float* mean,
+                               const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                               float* dres_colsum, int dt, long long rows, int D, void* stream);
+
 /* Multi-head self-attention core (mymodel/ViT.py:96-103): qkv is [B,N,3*H*DH] laid out as
  * the to_qkv output (q | k | v, each head-major), out is [B,N,H*DH] ('b h n d -> b n (h d)').
  * scores = (q k^T) * DH^-0.5 (scale after the matmul), softmax over keys, out = probs v.

@@ -67,6 +67,7 @@ SIGNATURES = {
     "vitmi_layernorm_fwd": (I, [P, L, P, P, P, P, P, I, L, I, F, P]),
     "vitmi_layernorm_bwd_workspace_bytes": (L, [L, I]),
     "vitmi_layernorm_bwd": (I, [P, P, L, P, P, P, P, P, P, P, P, P, I, L, I, P]),
+    "vitmi_layernorm_bwd_static": (I, [P, P, L, P, P, P, P, P, P, P, P, I, L, I, P]),
     "vitmi_attn_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vitmi_attn_bwd_workspace_bytes": (L, [I, I, I, I, I]),
     "vitmi_attn_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),

@@ -934,29 +934,25 @@ extern "C" long long vitmi_layernorm_bwd_workspace_bytes(long long rows, int D) 
     return (long long)ln_bwd_blocks(rows) * 3 * D * (long long)sizeof(float);
 }
 
-extern "C" int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx, const float* gamma, const float* mean,
-                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                   float* dres_colsum, void* workspace, int dt, long long rows, int D,
-                                   void* stream) {
-    VITMI_CHECK_ARG(!dres_colsum || dres, "vitmi_layernorm_bwd: dres_colsum needs dres");
-    VITMI_CHECK_ARG(dy && x && gamma && mean && rstd && dx && workspace, "vitmi_layernorm_bwd: null pointer");
-    VITMI_CHECK_ARG(rows > 0 && D > 0 && ldx >= D, "vitmi_layernorm_bwd: bad shape");
-    hipStream_t s = as_stream(stream);
+// shared body of vitmi_layernorm_bwd and vitmi_layernorm_bwd_static: `partial` is ln_bwd_blocks(rows) * 3 * D floats
+static int layernorm_bwd_launch(const char* who, const void* dy, const void* x, long long ldx, const float* gamma,
+                                const float* mean, const float* rstd, const void* dres, void* dx, float* dgamma,
+                                float* dbeta, float* dres_colsum, float* partial, int dt, long long rows, int D,
+                                hipStream_t s) {
     const int esz = dt == VITMI_F32 ? 4 : 2;
     ProfScope prof(VITMI_FAM_LAYERNORM, s, (dres ? 4.0 : 3.0) * rows * D * esz);
     const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && aligned_to(x, 16) && aligned_to(dy, 16) && aligned_to(dx, 16) &&
                      aligned_to(gamma, 16) && (!dres || aligned_to(dres, 16));
     const int iters = ceil_div(D, 64 * (vec ? 4 : 1));
     if (iters > 8) {
-        vitmi_set_error("vitmi_layernorm_bwd: D=%d exceeds the supported row length %d", D, 64 * 8 * (vec ? 4 : 1));
+        vitmi_set_error("%s: D=%d exceeds the supported row length %d", who, D, 64 * 8 * (vec ? 4 : 1));
         return VITMI_ERR_UNSUPPORTED;
     }
     if (dt != VITMI_F32 && dt != VITMI_BF16) {
-        vitmi_set_error("vitmi_layernorm_bwd: bad dtype %d", dt);
+        vitmi_set_error("%s: bad dtype %d", who, dt);
         return VITMI_ERR_BAD_ARG;
     }
     const int blocks = ln_bwd_blocks(rows);
-    float* partial = (float*)workspace;
     dim3 grid(blocks), block(256);
 #define LN_BWD(T, V, I)                                                                                        \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, V, I>), grid, block, 0, s, (const T*)dy, (const T*)x, ldx, gamma, \
@@ -977,13 +973,76 @@ extern "C" int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx,
     }
 #undef LN_BWD_I
 #undef LN_BWD
-    VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd");
+    VITMI_LAUNCH_CHECK(who);
     if (dgamma || dbeta || dres_colsum) {
         hipLaunchKernelGGL(layernorm_bwd_final_kernel, dim3(ceil_div(D, 64), 3), dim3(1024), 0, s, partial, blocks, D,
                            dgamma, dbeta, dres_colsum);
-        VITMI_LAUNCH_CHECK("vitmi_layernorm_bwd(final)");
+        VITMI_LAUNCH_CHECK(who);
     }
     return VITMI_OK;
+}
+
+extern "C" int vitmi_layernorm_bwd(const void* dy, const void* x, long long ldx, const float* gamma, const float* mean,
+                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                   float* dres_colsum, void* workspace, int dt, long long rows, int D,
+                                   void* stream) {
+    VITMI_CHECK_ARG(!dres_colsum || dres, "vitmi_layernorm_bwd: dres_colsum needs dres");
+    VITMI_CHECK_ARG(dy && x && gamma && mean && rstd && dx && workspace, "vitmi_layernorm_bwd: null pointer");
+    VITMI_CHECK_ARG(rows > 0 && D > 0 && ldx >= D, "vitmi_layernorm_bwd: bad shape");
+    return layernorm_bwd_launch("vitmi_layernorm_bwd", dy, x, ldx, gamma, mean, rstd, dres, dx, dgamma, dbeta,
+                                dres_colsum, (float*)workspace, dt, rows, D, as_stream(stream));
+}
+
+// ---- vitmi_layernorm_bwd_static: the same launches with the per-block partial sums in a device array of the
+// library instead of a caller workspace, so the call allocates nothing.  The array is sized for the largest grid
+// (768 blocks) at D <= VITMI_LN_BWD_STATIC_MAX_D; every GPU the library runs on holds one copy until the process
+// ends.  The array's name is only a host-side handle: its device address is looked up once per device with
+// hipGetSymbolAddress (the device current at that moment) and that pointer is what the kernels receive.
+static __device__ __align__(256) float g_ln_bwd_scratch[768 * 3 * VITMI_LN_BWD_STATIC_MAX_D];
+static float* g_ln_bwd_scratch_ptr[64] = {nullptr};
+
+static int ln_bwd_scratch(float** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return vitmi_hip_fail(e, "hipGetDevice");
+    if (dev < 0 || dev >= 64) {
+        vitmi_set_error("vitmi_layernorm_bwd_static: device index %d beyond the 64 the library tracks", dev);
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    float* p = __atomic_load_n(&g_ln_bwd_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        // two threads racing here look up the same address; neither allocates
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_ln_bwd_scratch));
+        if (e != hipSuccess) return vitmi_hip_fail(e, "hipGetSymbolAddress(layernorm scratch)");
+        if (!p) {
+            vitmi_set_error("vitmi_layernorm_bwd_static: no device address for the scratch array");
+            return VITMI_ERR_HIP;
+        }
+        __atomic_store_n(&g_ln_bwd_scratch_ptr[dev], p, __ATOMIC_RELEASE);
+    }
+    *out = p;
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_layernorm_bwd_static(const void* dy, const void* x, long long ldx, const float* gamma,
+                                          const float* mean, const float* rstd, const void* dres, void* dx,
+                                          float* dgamma, float* dbeta, float* dres_colsum, int dt, long long rows,
+                                          int D, void* stream) {
+    VITMI_CHECK_ARG(!dres_colsum || dres, "vitmi_layernorm_bwd_static: dres_colsum needs dres");
+    VITMI_CHECK_ARG(dy && x && gamma && mean && rstd && dx, "vitmi_layernorm_bwd_static: null pointer");
+    VITMI_CHECK_ARG(rows > 0 && D > 0 && ldx >= D, "vitmi_layernorm_bwd_static: bad shape");
+    if (D > VITMI_LN_BWD_STATIC_MAX_D) {
+        vitmi_set_error("vitmi_layernorm_bwd_static: D=%d exceeds the static scratch (rows of at most %d); use "
+                        "vitmi_layernorm_bwd with a workspace", D, VITMI_LN_BWD_STATIC_MAX_D);
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    float* partial = nullptr;
+    int rc = ln_bwd_scratch(&partial);
+    if (rc != VITMI_OK) return rc;
+    // every word of the scratch that the final kernel reads is written by the first kernel of this call, so nothing
+    // has to be cleared; two calls in flight on one GPU (different streams) would share it and race
+    return layernorm_bwd_launch("vitmi_layernorm_bwd_static", dy, x, ldx, gamma, mean, rstd, dres, dx, dgamma, dbeta,
+                                dres_colsum, partial, dt, rows, D, as_stream(stream));
 }
 
 extern "C" int vitmi_meanpool_fwd(const void* x, void* out, int dt, int B, int N, int D, void* stream) {
