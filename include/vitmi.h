@@ -112,6 +112,14 @@ int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long long ldu, 
 /* Tuning hook: force the block-tile configuration of the aligned nt GEMM (0 = 128x128, 1 = 256x128,
  * 2 = 256x256; -1 = automatic).  Process-wide; for benchmarking only. */
 int vitmi_debug_set_nt_config(int cfg);
+/* Tile walk of the persistent 256x256 nt kernel: gm > 0 = groups of gm row panels with the row index moving
+ * fastest inside a group (keeps the group's A panels in the XCD's L2 while it sweeps the weight), 0 = column index
+ * fastest, -1 = automatic.  Process-wide; for benchmarking only. */
+int vitmi_debug_set_nt_group(int gm);
+/* Start-up stagger of the persistent nt kernel's blocks, in ticks of the 100 MHz constant clock: blocks that own
+ * one tile fewer than the busiest ones start up to span (by position inside the XCD) + xspan (by XCD) ticks late.
+ * 0, 0 = off.  Process-wide; for benchmarking only. */
+int vitmi_debug_set_nt_stagger(int span_ticks, int xspan_ticks);
 /* same for the weight-gradient (tn) GEMM: 0 = 128x128, 1 = 256x256, -1 = automatic */
 int vitmi_debug_set_tn_config(int cfg);
 

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Start-up stagger of the persistent nt kernel (vitmi_debug_set_nt_stagger) on the encoder shapes, every epilogue:
+microseconds per launch by (span, xspan) in 10 ns ticks."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from visiontransformer_amd import ops  # noqa: E402
+from visiontransformer_amd._lib import BF16, EPI_DGELU, EPI_GELU, lib  # noqa: E402
+
+T = 256 * 197
+bf = torch.bfloat16
+GM = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+SP = [(0, 0), (800, 0), (1600, 0), (2400, 0), (3200, 0), (0, 1600), (0, 2400), (1600, 1600), (2400, 2400)]
+
+
+def timed(fn, n=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+lib.vitmi_debug_set_nt_group(GM)
+print("columns:", SP)
+for (N, K) in [(3072, 768), (2304, 768), (768, 3072), (768, 2304), (768, 768)]:
+    x = torch.randn(T, K, device="cuda").to(bf)
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).to(bf)
+    bias = torch.randn(N, device="cuda")
+    res = torch.randn(T, N, device="cuda").to(bf)
+    aux = torch.randn(T, N, device="cuda").to(bf)
+    y = torch.empty(T, N, device="cuda", dtype=bf)
+    cases = {
+        "plain": lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16),
+        "bias+res": lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, bias=bias, res=res, ldr=N),
+    }
+    if N == 3072:
+        cases["gelu+aux"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_GELU, bias=bias,
+                                                 aux=aux, ldaux=N)
+        cases["dgelu"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_DGELU, aux=aux,
+                                              ldaux=N)
+    for name, fn in cases.items():
+        line = f"N={N} K={K} {name:9s}:"
+        for sp in SP:
+            lib.vitmi_debug_set_nt_stagger(*sp)
+            line += f" {timed(fn) * 1e3:6.1f}"
+        print(line, flush=True)
+lib.vitmi_debug_set_nt_stagger(0, 0)
+lib.vitmi_debug_set_nt_group(-1)

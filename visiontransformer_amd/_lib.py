@@ -37,6 +37,8 @@ SIGNATURES = {
     "vitmi_transpose_cast": (I, [P, I, P, I, I, P]),
     "vitmi_debug_set_nt_config": (I, [I]),
     "vitmi_debug_set_tn_config": (I, [I]),
+    "vitmi_debug_set_nt_group": (I, [I]),
+    "vitmi_debug_set_nt_stagger": (I, [I, I]),
     "vitmi_colsum_workspace_bytes": (L, [L, I]),
     "vitmi_colsum": (I, [P, I, L, I, L, P, P, P]),
     "vitmi_patchify": (I, [P, I, P, I, I, I, I, I, I, P]),

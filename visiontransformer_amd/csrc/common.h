@@ -77,26 +77,32 @@ __device__ __forceinline__ float wave_max(float v) {
 // polynomial.  Used by the bf16 epilogues, where the result is rounded to 8 bits of mantissa;
 // the fp32 path keeps libm's erff.  Returns erf(x/sqrt2) and exp(-x^2/2) together because GELU
 // and its derivative need both.
+// Every multiply-add below is written as an explicit fmaf and contraction of the remaining operations is switched
+// off, so the value does not depend on how the compiler happens to vectorise the calling epilogue (two
+// instantiations of one kernel otherwise disagreed in the last bit of a few elements).
 __device__ __forceinline__ void erf_exp_fast(float x, float& erf_v, float& e) {
+#pragma clang fp contract(off)
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);  // exp(-x^2/2)
+    e = __builtin_amdgcn_exp2f((-0.72134752044448170368f * x) * x);  // exp(-x^2/2)
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
     p = fmaf(p, t, 0.254829592f);
-    const float r = 1.0f - p * t * e;
+    const float r = fmaf(-(p * t), e, 1.0f);
     erf_v = copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_fast(float x) {
+#pragma clang fp contract(off)
     float er, e;
     erf_exp_fast(x, er, e);
-    return 0.5f * x * (1.0f + er);
+    return (0.5f * x) * (1.0f + er);
 }
 __device__ __forceinline__ float gelu_grad_fast(float x) {
+#pragma clang fp contract(off)
     float er, e;
     erf_exp_fast(x, er, e);
-    return 0.5f * (1.0f + er) + x * 0.39894228040143267794f * e;
+    return fmaf(x * 0.39894228040143267794f, e, fmaf(0.5f, er, 0.5f));
 }
 
 // exact-erf GELU and its derivative (nn.GELU() default form)

@@ -206,6 +206,100 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
     }
 }
 
+// Epilogue of a whole 128 x 64 wave sub-tile whose 64 columns are all inside the matrix (phased kernel; bf16 output).
+// The eight row groups used to run one after the other as [load operand, wait, compute, store], and on this
+// architecture stores and loads retire through one in-order counter, so every group's wait also waited for the
+// previous group's stores: 8-16 dependent memory round trips per tile with the matrix pipes idle.  Here the bias is
+// read once per tile and the row operand (residual, or the saved pre-activation of the dGELU form) of PD row groups
+// is requested before the first group is processed, group i + PD right after group i has been stored; all loads of
+// a group are older than every store issued after them, so the counted waits the compiler derives never wait for a
+// store.  Rows past M read row M - 1 (always present) and are not stored.
+template <int EPI, bool CS, bool HAS_OP>
+__device__ __forceinline__ void epi_subtile_fast(const FastEpi& e, f32x4 (&acc)[4][8], int mrow0, int n, int M,
+                                                 float* cs) {
+    constexpr int PD = CS ? 4 : 8;
+    f32x4 b[4];
+    if (e.bias) {
+        b[0] = *reinterpret_cast<const f32x4*>(e.bias + n);
+        b[1] = *reinterpret_cast<const f32x4*>(e.bias + n + 4);
+        b[2] = *reinterpret_cast<const f32x4*>(e.bias + n + 32);
+        b[3] = *reinterpret_cast<const f32x4*>(e.bias + n + 36);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bf16_t* op = (EPI == VITMI_EPI_DGELU) ? e.aux : e.res;
+    const long long ldop = (EPI == VITMI_EPI_DGELU) ? e.ldaux : e.ldr;
+    bf16x8 o[8][2];
+    auto fetch = [&](int i) {
+        const int m = min(mrow0 + 16 * i, M - 1);
+        const bf16_t* p = op + (long long)m * ldop + n;
+        o[i][0] = *reinterpret_cast<const bf16x8*>(p);
+        o[i][1] = *reinterpret_cast<const bf16x8*>(p + 32);
+    };
+    if (HAS_OP) {
+#pragma unroll
+        for (int i = 0; i < PD; ++i) fetch(i);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int m = mrow0 + 16 * i;
+        const bool live = m < M;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[j][i][r] + b[j][r];
+        if (EPI == VITMI_EPI_GELU) {
+            if (e.aux && live) {
+                bf16x8 p0, p1;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    p0[t] = (bf16_t)v[t];
+                    p1[t] = (bf16_t)v[8 + t];
+                }
+                bf16_t* a = e.aux + (long long)m * e.ldaux + n;
+                *reinterpret_cast<bf16x8*>(a) = p0;
+                *reinterpret_cast<bf16x8*>(a + 32) = p1;
+            }
+#pragma unroll
+            for (int t = 0; t < 16; ++t) v[t] = gelu_fast(v[t]);
+        }
+        if (HAS_OP) {
+            if (EPI == VITMI_EPI_DGELU) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    v[t] *= gelu_grad_fast((float)o[i][0][t]);
+                    v[8 + t] *= gelu_grad_fast((float)o[i][1][t]);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    v[t] += (float)o[i][0][t];
+                    v[8 + t] += (float)o[i][1][t];
+                }
+            }
+        }
+        if (live) {
+            bf16x8 p0, p1;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                p0[t] = (bf16_t)v[t];
+                p1[t] = (bf16_t)v[8 + t];
+            }
+            bf16_t* c = reinterpret_cast<bf16_t*>(e.C) + (long long)m * e.ldc + n;
+            *reinterpret_cast<bf16x8*>(c) = p0;
+            *reinterpret_cast<bf16x8*>(c + 32) = p1;
+            if (CS) {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) cs[t] += v[t];
+            }
+        }
+        if (HAS_OP && i + PD < 8) fetch(i + PD);
+    }
+}
+
 // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous
 // run of tiles; within a run the n-tile index moves fastest (neighbours share the A row panel).
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -328,7 +422,7 @@ template <int EPI, typename OutT, bool CS>
 __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __restrict__ A, long long lda,
                                                              const bf16_t* __restrict__ B, long long ldb,
                                                              FastEpi epi, int M, int N, int K, int tiles_n,
-                                                             int ntiles) {
+                                                             int ntiles, int gm, int span, int xspan) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int lane = threadIdx.x & 63;
@@ -336,11 +430,40 @@ __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __res
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int nreg = 4 * (K / TK);  // regions in the stream
+    const int tiles_m = ntiles / tiles_n;
+    // Optional start-up stagger (ticks of the 100 MHz constant clock): every block would otherwise reach its
+    // epilogue at the same moment, so the chip writes its outputs in bursts at fabric speed with the matrix pipes
+    // idle.  Only blocks that own one tile fewer than the busiest blocks are delayed (at most `span + xspan` ticks,
+    // chosen below one tile time), so the delay costs nothing.
+    if (span > 0 || xspan > 0) {
+        const int rem = ntiles % gridDim.x;
+        if (rem != 0 && (int)blockIdx.x >= rem) {
+            const unsigned long long d =
+                (unsigned long long)((long long)span * (blockIdx.x >> 3) / 32 + (long long)xspan * (blockIdx.x & 7) / 8);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+        }
+    }
     // persistent: the grid is one block per CU (a multiple of 8, so a block keeps its XCD); output
     // stores of a tile drain while the next tile's loads and MFMAs run
     for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
     const int tile = xcd_remap(vb, ntiles);
-    const int m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+    // Tile order inside an XCD's run.  gm == 0: n fastest (the blocks of an XCD share A row panels).  gm > 0: groups
+    // of gm row panels, m fastest inside a group, so the 32 blocks of an XCD work on gm row panels x 32/gm weight
+    // tiles at a time: the gm A panels stay in the XCD's L2 while the group sweeps the weight once, and a weight
+    // that does not fit the L2 is re-fetched once per group instead of once per row panel.
+    int tm, tn;
+    if (gm > 0) {
+        const int per = gm * tiles_n;
+        const int g = tile / per, r = tile - g * per;
+        const int ge = min(gm, tiles_m - g * gm);
+        tn = r / ge;
+        tm = g * gm + (r - tn * ge);
+    } else {
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+    }
+    const int m0 = tm * 256, n0 = tn * 256;
 
     // A region is 16 loads of 8 rows; wave w issues loads 2w and 2w+1 of every region.  src[s][i]:
     // per-lane source of load i of the next region of kind s (0 RA0, 1 RB0, 2 RB1, 3 RA1); rows
@@ -496,6 +619,22 @@ __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __res
 #pragma unroll
         for (int t = 0; t < 16; ++t) cs[t] = 0.f;
     }
+    // whole sub-tile inside the matrix in n, bf16 output, one row operand at most: the pipelined epilogue
+    const bool fast_epi = sizeof(OutT) == 2 && n0 + 256 <= N && epi.rows_per_group == 0 &&
+                          !(EPI != VITMI_EPI_NONE && epi.res);
+    if (fast_epi) {
+        const int mrow0 = m0 + wr * 128 + fr, nn = n0 + wc * 64 + 8 * fg;
+        if constexpr (EPI == VITMI_EPI_DGELU) {
+            epi_subtile_fast<EPI, CS, true>(epi, acc, mrow0, nn, M, cs);
+        } else if constexpr (EPI == VITMI_EPI_GELU) {
+            epi_subtile_fast<EPI, CS, false>(epi, acc, mrow0, nn, M, cs);
+        } else {
+            if (epi.res)
+                epi_subtile_fast<EPI, CS, true>(epi, acc, mrow0, nn, M, cs);
+            else
+                epi_subtile_fast<EPI, CS, false>(epi, acc, mrow0, nn, M, cs);
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         // with the column sums the register file is full here: keep hipcc from hoisting the operand
@@ -1068,6 +1207,10 @@ static int phased_grid_blocks() {
     return c;
 }
 
+static int pick_nt_group(int N, int K);
+static int nt_span();
+static int nt_xspan();
+
 template <int EPI, typename OutT>
 static int launch_nt_phased(int M, int N, int K, const bf16_t* a, long long lda, const bf16_t* b, long long ldb,
                             const FastEpi& e, hipStream_t s) {
@@ -1087,14 +1230,16 @@ static int launch_nt_phased(int M, int N, int K, const bf16_t* a, long long lda,
         auto fcs = gemm_nt_phased_kernel<VITMI_EPI_DGELU, bf16_t, true>;
         int rc = ensure_lds_attr(reinterpret_cast<const void*>(fcs), lds, &done_cs);
         if (rc != VITMI_OK) return rc;
-        hipLaunchKernelGGL(fcs, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles);
+        hipLaunchKernelGGL(fcs, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles,
+                           pick_nt_group(N, K), nt_span(), nt_xspan());
         VITMI_LAUNCH_CHECK("vitmi_gemm(nt phased + column sums)");
         return VITMI_OK;
     }
     auto fn = gemm_nt_phased_kernel<EPI, OutT, false>;
     int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
     if (rc != VITMI_OK) return rc;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles,
+                       pick_nt_group(N, K), nt_span(), nt_xspan());
     VITMI_LAUNCH_CHECK("vitmi_gemm(nt phased)");
     return VITMI_OK;
 }
@@ -1106,6 +1251,31 @@ extern "C" int vitmi_debug_set_nt_config(int cfg) {
     g_nt_cfg_override = cfg;
     return VITMI_OK;
 }
+
+// row panels per group of the phased kernel's tile walk: -1 = automatic, 0 = n fastest
+static int g_nt_group_override = -1;
+extern "C" int vitmi_debug_set_nt_group(int gm) {
+    g_nt_group_override = gm;
+    return VITMI_OK;
+}
+static int g_nt_span = 0, g_nt_xspan = 0;
+extern "C" int vitmi_debug_set_nt_stagger(int span_ticks, int xspan_ticks) {
+    g_nt_span = span_ticks;
+    g_nt_xspan = xspan_ticks;
+    return VITMI_OK;
+}
+static int pick_nt_group(int N, int K) {
+    if (g_nt_group_override >= 0) return g_nt_group_override;
+    (void)K;
+    // measured at 50432 rows (tools/gemm_group_cmp.py): 12 column tiles (N = 3072, a 4.7 MB weight that does not fit
+    // one XCD's L2) 295 -> 250-260 us with groups of 12; 9 column tiles (N = 2304) 175 -> 166 us with groups of 8;
+    // three column tiles: no difference
+    const int tiles_n = ceil_div(N, 256);
+    return tiles_n >= 12 ? 12 : (tiles_n >= 6 ? 8 : 0);
+}
+
+static int nt_span() { return g_nt_span; }
+static int nt_xspan() { return g_nt_xspan; }
 
 static int pick_nt_cfg(int M, int N) {
     if (g_nt_cfg_override >= 0) return g_nt_cfg_override;
