@@ -37,6 +37,12 @@ extern "C" {
 #define VITMI_EPI_NONE 0  /* C = acc [+ bias[n]] [+ residual(m,n)]                                  */
 #define VITMI_EPI_GELU 1  /* pre = acc + bias[n]; aux(m,n) = pre (if aux); C = gelu_erf(pre)        */
 #define VITMI_EPI_DGELU 2 /* C = acc * gelu_erf'(aux(m,n))   (aux = the pre-activation saved above) */
+/* The same pair with the derivative evaluated in the FORWARD epilogue, where erf and exp of the pre-activation
+ * are at hand anyway; the backward epilogue is then one multiply per element instead of an erf evaluation: */
+/* aux of this pair is private to it: fp32 in fp32 mode, IEEE half bits (not bf16) in bf16 mode, since the
+ * derivative lies in [-0.13, 1.13] and half keeps 11 significant bits of it. */
+#define VITMI_EPI_GELU_D 3 /* pre = acc + bias[n]; aux(m,n) = gelu_erf'(pre) (if aux); C = gelu_erf(pre)  */
+#define VITMI_EPI_MULAUX 4 /* C = acc * aux(m,n)                                                           */
 
 /* kernel families for the launch timers (vitmi_prof_*) */
 #define VITMI_FAM_GEMM 0
@@ -117,9 +123,13 @@ int vitmi_debug_set_nt_config(int cfg);
  * fastest, -1 = automatic.  Process-wide; for benchmarking only. */
 int vitmi_debug_set_nt_group(int gm);
 /* Start-up stagger of the persistent nt kernel's blocks, in ticks of the 100 MHz constant clock: blocks that own
- * one tile fewer than the busiest ones start up to span (by position inside the XCD) + xspan (by XCD) ticks late.
- * 0, 0 = off.  Process-wide; for benchmarking only. */
-int vitmi_debug_set_nt_stagger(int span_ticks, int xspan_ticks);
+ * one tile fewer than the busiest ones (all_blocks != 0: every block) start up to span (by position inside the
+ * XCD) + xspan (by XCD) ticks late.  0, 0 = off.  Process-wide; for benchmarking only. */
+int vitmi_debug_set_nt_stagger(int span_ticks, int xspan_ticks, int all_blocks);
+/* Epilogue pair of vitmi_ff_block_fwd/bwd: 0 (default) = VITMI_EPI_GELU_D / VITMI_EPI_MULAUX, 1 = VITMI_EPI_GELU /
+ * VITMI_EPI_DGELU.  Process-wide and to be left alone between a forward pass and its backward pass; for
+ * benchmarking and error studies only. */
+int vitmi_debug_set_gelu_pair(int classic);
 /* same for the weight-gradient (tn) GEMM: 0 = 128x128, 1 = 256x256, -1 = automatic */
 int vitmi_debug_set_tn_config(int cfg);
 
@@ -256,7 +266,8 @@ int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const flo
  * the entry points above; they exist so that the host pays one foreign call per sub-block instead of one per
  * kernel.  All matrices are dense row-major in dt (weights as nn.Linear stores them, [out, in]); gamma, beta,
  * biases, mean, rstd, lse and every parameter gradient are fp32.  Saved for backward: xn (normalised input),
- * mean, rstd, and u / h (MLP pre-activation and activation) or qkv / o / lse.  w*_t: optional transposed copies
+ * mean, rstd, and u / h (derivative of GELU at the MLP pre-activation, written by the forward epilogue
+ * VITMI_EPI_GELU_D and multiplied in by VITMI_EPI_MULAUX in the backward pass, and the activation) or qkv / o / lse.  w*_t: optional transposed copies
  * [in, out] of the weights for the input-gradient products (NULL: read through strides).  b_qkv, b_out, db_qkv,
  * db_out and probs may be NULL.  workspace: the matching *_workspace_bytes (temporaries + scratch of the steps). */
 int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x, const float* gamma, const float* beta, float eps,

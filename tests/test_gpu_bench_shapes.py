@@ -31,6 +31,12 @@ def q(t):
     return t.to(BF).float()
 
 
+def deriv(t):
+    """the derivative buffer of the GELU_D / MULAUX pair as fp32: IEEE half bits in a bf16-typed tensor, plain fp32
+    in fp32 mode"""
+    return t.view(torch.float16).float() if t.dtype == torch.bfloat16 else t.float()
+
+
 @pytest.fixture(scope="module")
 def ops():
     from visiontransformer_amd import ops as o
@@ -58,6 +64,11 @@ def test_phased_nt_gemm_forward_epilogues_at_bench_shapes(ops, M, N, K):
         h, u = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_GELU, want_aux=True)
         assert rel_err(u, pre + b) < 1e-2
         assert rel_err(h, vit_oracle.gelu_erf(pre + b)) < 1e-2
+        # <GELU_D,bf16>: the form the MLP block runs -- aux receives gelu'(pre) instead of pre
+        h2, gp = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_GELU_D, want_aux=True)
+        pr = (pre + b).requires_grad_(True)
+        vit_oracle.gelu_erf(pr).sum().backward()
+        assert torch.equal(h2, h) and rel_err(deriv(gp), pr.grad) < 1e-2
     if N == 768 and K == 768:
         y32, _ = ops.linear_fwd(xd, wd, bd, out_dtype=torch.float32)
         assert rel_err(y32, pre + b) < 2e-3
@@ -88,6 +99,15 @@ def test_phased_nt_gemm_input_gradients_at_bench_shapes(ops, M, N, K):
     assert torch.equal(du2, du)
     assert rel_err(cs, a.grad.double().sum(0)) < 1e-2
     assert rel_err(cs, du.double().sum(0)) < 2e-3          # sums of the unrounded values vs sums of their bf16
+    # <MULAUX,bf16,false/true>: the backward half of the pair above (aux holds the derivative itself)
+    auxh = aux.half().to(DEV).view(BF)                              # the pair keeps its aux as IEEE half bits
+    gref = ref * aux.half().float()
+    dm = ops.linear_bwd_x(dyd, wd, epi=ops.EPI_MULAUX, aux=auxh, w_t=wt)
+    assert rel_err(dm, gref) < 1e-2
+    dm2, csm = ops.linear_bwd_x(dyd, wd, epi=ops.EPI_MULAUX, aux=auxh, w_t=wt, want_colsum=True)
+    assert torch.equal(dm2, dm)
+    assert rel_err(csm, gref.double().sum(0)) < 1e-4          # fp32 sums of the unrounded products
+    assert rel_err(csm, dm.double().sum(0)) < 5e-3            # ... against sums of their bf16 roundings
 
 
 @pytest.mark.parametrize("T,P,Q", [(M_BENCH, 2304, 768), (M_BENCH, 768, 768), (M_BENCH, 3072, 768),

@@ -17,6 +17,12 @@ DEV = "cuda:0"
 TOL = {torch.float32: 1e-4, torch.bfloat16: 2e-2}
 
 
+def deriv(t):
+    """the derivative buffer of the GELU_D / MULAUX pair as fp32: IEEE half bits in a bf16-typed tensor, plain fp32
+    in fp32 mode"""
+    return t.view(torch.float16).float() if t.dtype == torch.bfloat16 else t.float()
+
+
 @pytest.fixture(scope="module")
 def ops():
     from visiontransformer_amd import ops as o
@@ -73,6 +79,13 @@ def test_gemm_epilogues(ops, dtype):
     # fp32 output from bf16 operands with bias (the classifier head)
     y32, _ = ops.linear_fwd(xd, wd, bd, out_dtype=torch.float32)
     assert y32.dtype == torch.float32 and rel_err(y32, pre) < (1e-4 if dtype == torch.float32 else 2e-3)
+    # the same pair with the derivative evaluated in the forward epilogue and multiplied in by the backward one
+    h2, gp = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_GELU_D, want_aux=True)
+    pr = pre.clone().requires_grad_(True)
+    vit_oracle.gelu_erf(pr).sum().backward()
+    assert rel_err(h2, vit_oracle.gelu_erf(pre)) < TOL[dtype] and rel_err(deriv(gp), pr.grad) < TOL[dtype]
+    du2 = ops.linear_bwd_x(dy.to(DEV, dtype), w2.to(DEV, dtype), epi=ops.EPI_MULAUX, aux=gp)
+    assert rel_err(du2, (q(dy, dtype) @ q(w2, dtype)) * deriv(gp).cpu()) < TOL[dtype]
 
 
 def test_gemm_strided_views_and_unaligned(ops):
@@ -293,6 +306,16 @@ def test_fast_nt_gemm_all_epilogues(ops, M, N, K):
     assert rel_err(cs, du.float().sum(0)) < 2e-3          # sums of the unrounded values vs sums of bf16
     _, cs2 = ops.linear_bwd_x(dy.to(DEV, dtype), wd, epi=ops.EPI_DGELU, aux=aux, w_t=wt, want_colsum=True)
     assert torch.equal(cs, cs2)                            # fixed summation order
+    # derivative stored by the forward epilogue (GELU_D), multiplied in by the backward one (MULAUX)
+    h2, gp = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_GELU_D, want_aux=True)
+    pr = pre.clone().requires_grad_(True)
+    vit_oracle.gelu_erf(pr).sum().backward()
+    assert torch.equal(h2, h) and rel_err(deriv(gp), pr.grad) < 1e-2
+    auxh = aux.float().half().view(torch.bfloat16)                 # the pair keeps its aux as IEEE half bits
+    dm = ops.linear_bwd_x(dy.to(DEV, dtype), wd, epi=ops.EPI_MULAUX, aux=auxh, w_t=wt)
+    assert rel_err(dm, (q(dy, dtype) @ q(w, dtype)) * deriv(auxh).cpu()) < 1e-2
+    dm2, csm = ops.linear_bwd_x(dy.to(DEV, dtype), wd, epi=ops.EPI_MULAUX, aux=auxh, w_t=wt, want_colsum=True)
+    assert torch.equal(dm2, dm) and rel_err(csm, dm.float().sum(0)) < 2e-3
 
 
 # T % 64 == 0 with P, Q >= 512 takes the phased kernel (ragged P and Q edges, one and two token tiles)

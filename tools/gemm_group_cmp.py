@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from visiontransformer_amd import ops  # noqa: E402
-from visiontransformer_amd._lib import BF16, EPI_DGELU, EPI_GELU, lib  # noqa: E402
+from visiontransformer_amd._lib import BF16, EPI_DGELU, EPI_GELU, EPI_GELU_D, EPI_MULAUX, lib  # noqa: E402
 
 T = 256 * 197
 bf = torch.bfloat16
@@ -42,6 +42,10 @@ for (N, K) in [(3072, 768), (2304, 768), (768, 3072), (768, 2304), (768, 768)]:
     if N == 3072:
         cases["gelu+aux"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_GELU, bias=bias,
                                                  aux=aux, ldaux=N)
+        cases["gelu_d"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_GELU_D, bias=bias,
+                                               aux=aux, ldaux=N)
+        cases["mulaux"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_MULAUX, aux=aux,
+                                               ldaux=N)
         cases["dgelu"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_DGELU, aux=aux,
                                               ldaux=N)
     for name, fn in cases.items():
@@ -53,7 +57,7 @@ for (N, K) in [(3072, 768), (2304, 768), (768, 3072), (768, 2304), (768, 768)]:
             out = y.clone()
             if ref is None:
                 ref = out
-            ok = torch.equal(out, ref) or name == "gelu+aux"
+            ok = torch.equal(out, ref) or name in ("gelu+aux", "gelu_d")
             us = timed(fn) * 1e3
             line += f"  gm{gm} {us:6.1f}us{'' if ok else ' MISMATCH'}"
         print(line, flush=True)

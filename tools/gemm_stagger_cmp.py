@@ -8,12 +8,13 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from visiontransformer_amd import ops  # noqa: E402
-from visiontransformer_amd._lib import BF16, EPI_DGELU, EPI_GELU, lib  # noqa: E402
+from visiontransformer_amd._lib import BF16, EPI_GELU_D, EPI_MULAUX, lib  # noqa: E402
 
 T = 256 * 197
 bf = torch.bfloat16
-GM = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-SP = [(0, 0), (800, 0), (1600, 0), (2400, 0), (3200, 0), (0, 1600), (0, 2400), (1600, 1600), (2400, 2400)]
+GM = int(sys.argv[1]) if len(sys.argv) > 1 else -1
+SP = [(0, 0, 0), (0, 1200, 0), (0, 2400, 0), (0, 3600, 0), (0, 4800, 0), (0, 7200, 0), (0, 600, 1), (0, 1200, 1),
+      (0, 2400, 1), (400, 2400, 0)]
 
 
 def timed(fn, n=20):
@@ -43,15 +44,15 @@ for (N, K) in [(3072, 768), (2304, 768), (768, 3072), (768, 2304), (768, 768)]:
         "bias+res": lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, bias=bias, res=res, ldr=N),
     }
     if N == 3072:
-        cases["gelu+aux"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_GELU, bias=bias,
-                                                 aux=aux, ldaux=N)
-        cases["dgelu"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_DGELU, aux=aux,
-                                              ldaux=N)
+        cases["gelu_d"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_GELU_D, bias=bias,
+                                               aux=aux, ldaux=N)
+        cases["mulaux"] = lambda: ops.gemm_raw(BF16, T, N, K, x, K, 1, w, K, 1, y, N, BF16, epi=EPI_MULAUX, aux=aux,
+                                               ldaux=N)
     for name, fn in cases.items():
         line = f"N={N} K={K} {name:9s}:"
         for sp in SP:
             lib.vitmi_debug_set_nt_stagger(*sp)
             line += f" {timed(fn) * 1e3:6.1f}"
         print(line, flush=True)
-lib.vitmi_debug_set_nt_stagger(0, 0)
+lib.vitmi_debug_set_nt_stagger(0, 0, 0)
 lib.vitmi_debug_set_nt_group(-1)

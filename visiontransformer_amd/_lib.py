@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvitmi_hip.so")
 
 F32, BF16 = 0, 1
-EPI_NONE, EPI_GELU, EPI_DGELU = 0, 1, 2
+EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_D, EPI_MULAUX = 0, 1, 2, 3, 4
 FAM_GEMM, FAM_ATTN_FWD, FAM_ATTN_BWD, FAM_LAYERNORM, FAM_TOKENS, FAM_OTHER = range(6)
 FAM_GEMM_VARIANT0, FAM_COUNT = 8, 29
 
@@ -38,7 +38,8 @@ SIGNATURES = {
     "vitmi_debug_set_nt_config": (I, [I]),
     "vitmi_debug_set_tn_config": (I, [I]),
     "vitmi_debug_set_nt_group": (I, [I]),
-    "vitmi_debug_set_nt_stagger": (I, [I, I]),
+    "vitmi_debug_set_gelu_pair": (I, [I]),
+    "vitmi_debug_set_nt_stagger": (I, [I, I, I]),
     "vitmi_colsum_workspace_bytes": (L, [L, I]),
     "vitmi_colsum": (I, [P, I, L, I, L, P, P, P]),
     "vitmi_patchify": (I, [P, I, P, I, I, I, I, I, I, P]),

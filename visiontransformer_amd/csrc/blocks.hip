@@ -34,6 +34,13 @@ int input_grad(int dt, int T, int K, int N, const void* dy, const void* w, const
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ MLP block
+// which epilogue pair the MLP block runs: 0 = GELU_D / MULAUX (u holds gelu'(pre-activation)), 1 = GELU / DGELU (u
+// holds the pre-activation and the backward epilogue evaluates the derivative)
+static int g_classic_gelu_pair = 0;
+extern "C" int vitmi_debug_set_gelu_pair(int classic) {
+    g_classic_gelu_pair = classic ? 1 : 0;
+    return VITMI_OK;
+}
 extern "C" int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x, const float* gamma, const float* beta,
                                   float eps, const void* w1, const float* b1, const void* w2, const float* b2, void* xn,
                                   float* mean, float* rstd, void* u, void* h, void* y, void* stream) {
@@ -41,7 +48,8 @@ extern "C" int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x,
                     "vitmi_ff_block_fwd: null pointer");
     VITMI_CHECK_ARG(rows > 0 && D > 0 && M > 0, "vitmi_ff_block_fwd: bad shape rows=%d D=%d M=%d", rows, D, M);
     STEP(vitmi_layernorm_fwd(x, D, gamma, beta, xn, mean, rstd, dt, rows, D, eps, stream));
-    STEP(vitmi_gemm(dt, rows, M, D, xn, D, 1, w1, D, 1, h, M, dt, VITMI_EPI_GELU, b1, nullptr, 0, u, M, stream));
+    STEP(vitmi_gemm(dt, rows, M, D, xn, D, 1, w1, D, 1, h, M, dt, g_classic_gelu_pair ? VITMI_EPI_GELU : VITMI_EPI_GELU_D, b1, nullptr, 0, u,
+                    M, stream));
     STEP(vitmi_gemm(dt, rows, D, M, h, M, 1, w2, M, 1, y, D, dt, VITMI_EPI_NONE, b2, x, D, nullptr, 0, stream));
     return VITMI_OK;
 }
@@ -69,7 +77,8 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
     void* dxn = ws + align256((long long)rows * M * esize(dt));
     void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
     STEP(vitmi_gemm_wgrad(dt, D, M, rows, dy, D, h, M, dw2, M, scratch, stream));
-    STEP(input_grad(dt, rows, M, D, dy, w2, w2_t, du, VITMI_EPI_DGELU, const_cast<void*>(u), db1, scratch, stream));
+    STEP(input_grad(dt, rows, M, D, dy, w2, w2_t, du, g_classic_gelu_pair ? VITMI_EPI_DGELU : VITMI_EPI_MULAUX,
+                    const_cast<void*>(u), db1, scratch, stream));
     STEP(vitmi_gemm_wgrad(dt, M, D, rows, du, M, xn, D, dw1, D, scratch, stream));
     STEP(input_grad(dt, rows, D, M, du, w1, w1_t, dxn, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
     STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db2, scratch, dt, rows, D, stream));

@@ -50,6 +50,17 @@ struct ProfScope {
     ~ProfScope() { vitmi_prof_record_end(fam, s); }
 };
 
+// The derivative that VITMI_EPI_GELU_D hands to VITMI_EPI_MULAUX lies in [-0.13, 1.13]: in the 16-bit modes it is
+// kept as IEEE half (11 significant bits, no range problem) inside the bf16-typed buffer rather than as bf16 (8 bits),
+// whose rounding showed up in the LayerNorm-weight gradients.  fp32 mode keeps it in fp32.
+__device__ __forceinline__ __bf16 deriv_pack(float v, __bf16) { return __builtin_bit_cast(__bf16, (_Float16)v); }
+__device__ __forceinline__ float deriv_pack(float v, float) { return v; }
+__device__ __forceinline__ float deriv_unpack(__bf16 b) { return (float)__builtin_bit_cast(_Float16, b); }
+__device__ __forceinline__ float deriv_unpack(float v) { return v; }
+
+constexpr bool epi_is_gelu(int epi) { return epi == VITMI_EPI_GELU || epi == VITMI_EPI_GELU_D; }
+constexpr bool epi_is_auxmul(int epi) { return epi == VITMI_EPI_DGELU || epi == VITMI_EPI_MULAUX; }
+
 // ---- dtype traits --------------------------------------------------------------------------
 template <typename T> struct dt_of;
 template <> struct dt_of<float> { static constexpr int value = VITMI_F32; };
@@ -97,6 +108,13 @@ __device__ __forceinline__ float gelu_fast(float x) {
     float er, e;
     erf_exp_fast(x, er, e);
     return (0.5f * x) * (1.0f + er);
+}
+__device__ __forceinline__ void gelu_both_fast(float x, float& g, float& dg) {
+#pragma clang fp contract(off)
+    float er, e;
+    erf_exp_fast(x, er, e);
+    g = (0.5f * x) * (1.0f + er);
+    dg = fmaf(x * 0.39894228040143267794f, e, fmaf(0.5f, er, 0.5f));
 }
 __device__ __forceinline__ float gelu_grad_fast(float x) {
 #pragma clang fp contract(off)

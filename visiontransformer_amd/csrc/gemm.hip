@@ -60,11 +60,14 @@ struct Epilogue {
 template <int EPI, typename T, typename OutT>
 __device__ __forceinline__ void epilogue_store(const Epilogue& e, int m, int n, float v) {
     if (e.bias) v += e.bias[n];
-    if (EPI == VITMI_EPI_GELU) {
-        if (e.aux) reinterpret_cast<T*>(e.aux)[(long long)m * e.ldaux + n] = from_f32<T>(v);
+    if (epi_is_gelu(EPI)) {
+        if (e.aux)
+            reinterpret_cast<T*>(e.aux)[(long long)m * e.ldaux + n] =
+                EPI == VITMI_EPI_GELU_D ? deriv_pack(gelu_erf_grad(v), T()) : from_f32<T>(v);
         v = gelu_erf(v);
-    } else if (EPI == VITMI_EPI_DGELU) {
-        v *= gelu_erf_grad(to_f32(reinterpret_cast<const T*>(e.aux)[(long long)m * e.ldaux + n]));
+    } else if (epi_is_auxmul(EPI)) {
+        const T a = reinterpret_cast<const T*>(e.aux)[(long long)m * e.ldaux + n];
+        v *= (EPI == VITMI_EPI_MULAUX) ? deriv_unpack(a) : gelu_erf_grad(to_f32(a));
     }
     if (e.res) v += to_f32(reinterpret_cast<const T*>(e.res)[(long long)m * e.ldr + n]);
     long long off;
@@ -364,8 +367,8 @@ static int gemm_impl(int dt, int M, int N, int K, const void* A, long long sam, 
     VITMI_CHECK_ARG(A && B && C, "vitmi_gemm: null operand");
     VITMI_CHECK_ARG(M > 0 && N > 0 && K > 0, "vitmi_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     VITMI_CHECK_ARG(ldc >= N, "vitmi_gemm: ldc=%lld < N=%d", ldc, N);
-    VITMI_CHECK_ARG(epilogue >= VITMI_EPI_NONE && epilogue <= VITMI_EPI_DGELU, "vitmi_gemm: bad epilogue %d", epilogue);
-    VITMI_CHECK_ARG(epilogue != VITMI_EPI_DGELU || aux, "vitmi_gemm: dGELU epilogue needs aux");
+    VITMI_CHECK_ARG(epilogue >= VITMI_EPI_NONE && epilogue <= VITMI_EPI_MULAUX, "vitmi_gemm: bad epilogue %d", epilogue);
+    VITMI_CHECK_ARG(!epi_is_auxmul(epilogue) || aux, "vitmi_gemm: this epilogue needs aux");
     VITMI_CHECK_ARG(!residual || ldr >= N, "vitmi_gemm: ldr=%lld < N=%d", ldr, N);
     VITMI_CHECK_ARG(!aux || ldaux >= N, "vitmi_gemm: ldaux=%lld < N=%d", ldaux, N);
     VITMI_CHECK_ARG(sam >= 0 && sak >= 0 && sbn >= 0 && sbk >= 0, "vitmi_gemm: strides must not be negative");
@@ -377,7 +380,7 @@ static int gemm_impl(int dt, int M, int N, int K, const void* A, long long sam, 
         VITMI_CHECK_ARG(c_dt == VITMI_BF16 || (c_dt == VITMI_F32 && epilogue == VITMI_EPI_NONE),
                         "vitmi_gemm: fp32 output supports only the plain epilogue");
         const int layout = ((sam == 1 && sak != 1) ? 2 : 0) + ((sbn == 1 && sbk != 1) ? 1 : 0);
-        const int eo = c_dt == VITMI_F32 ? 1 : (epilogue == VITMI_EPI_GELU ? 2 : (epilogue == VITMI_EPI_DGELU ? 3 : 0));
+        const int eo = c_dt == VITMI_F32 ? 1 : (epi_is_gelu(epilogue) ? 2 : (epi_is_auxmul(epilogue) ? 3 : 0));
         fam = VITMI_FAM_GEMM_VARIANT0 + 4 * layout + eo;
         fast_nt = sak == 1 && sbk == 1 &&
                   vitmi_gemm_nt_fast_ok(M, N, K, A, sam, B, sbn, C, ldc, c_dt, residual, ldr, aux, ldaux);
@@ -396,6 +399,10 @@ static int gemm_impl(int dt, int M, int N, int K, const void* A, long long sam, 
             hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
         else if (epilogue == VITMI_EPI_GELU)
             hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+        else if (epilogue == VITMI_EPI_GELU_D)
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU_D>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+        else if (epilogue == VITMI_EPI_MULAUX)
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_MULAUX>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
         else
             hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_DGELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
         VITMI_LAUNCH_CHECK("vitmi_gemm(f32)");
@@ -411,6 +418,10 @@ static int gemm_impl(int dt, int M, int N, int K, const void* A, long long sam, 
         dispatch_bf16_layout<VITMI_EPI_NONE, bf16_t>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
     else if (epilogue == VITMI_EPI_GELU)
         dispatch_bf16_layout<VITMI_EPI_GELU, bf16_t>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
+    else if (epilogue == VITMI_EPI_GELU_D)
+        dispatch_bf16_layout<VITMI_EPI_GELU_D, bf16_t>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
+    else if (epilogue == VITMI_EPI_MULAUX)
+        dispatch_bf16_layout<VITMI_EPI_MULAUX, bf16_t>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
     else
         dispatch_bf16_layout<VITMI_EPI_DGELU, bf16_t>(a_kc, b_kc, A, sam, sak, B, sbn, sbk, epi, M, N, K, s);
     VITMI_LAUNCH_CHECK("vitmi_gemm(bf16)");
@@ -439,7 +450,7 @@ extern "C" int vitmi_gemm_colsum(int dt, int M, int N, int K, const void* A, lon
     VITMI_CHECK_ARG(colsum && workspace, "vitmi_gemm_colsum: null colsum or workspace");
     VITMI_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "vitmi_gemm_colsum: bad operands");
     hipStream_t s = as_stream(stream);
-    const bool fused = dt == VITMI_BF16 && c_dt == VITMI_BF16 && epilogue == VITMI_EPI_DGELU && sak == 1 && sbk == 1 &&
+    const bool fused = dt == VITMI_BF16 && c_dt == VITMI_BF16 && epi_is_auxmul(epilogue) && sak == 1 && sbk == 1 &&
                        vitmi_gemm_nt_fast_ok(M, N, K, A, sam, B, sbn, C, ldc, c_dt, residual, ldr, aux, ldaux) &&
                        vitmi_gemm_nt_phased_ok(M, N, K);
     int rc = gemm_impl(dt, M, N, K, A, sam, sak, B, sbn, sbk, C, ldc, c_dt, epilogue, bias, residual, ldr, aux, ldaux,

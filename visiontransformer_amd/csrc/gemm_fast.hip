@@ -125,40 +125,50 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
                 if (col(t) < N) v[t] += e.bias[col(t)];
         }
     }
-    if (EPI == VITMI_EPI_GELU) {
+    if (epi_is_gelu(EPI)) {
+        float w[16];  // what aux receives: the pre-activation, or the derivative of GELU at it
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (EPI == VITMI_EPI_GELU_D) {
+                gelu_both_fast(v[t], v[t], w[t]);
+            } else {
+                w[t] = v[t];
+                v[t] = gelu_fast(v[t]);
+            }
+        }
         if (e.aux) {
             bf16_t* a = e.aux + (long long)m * e.ldaux + n;
             if (full) {
                 bf16x8 p0, p1;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    p0[t] = (bf16_t)v[t];
-                    p1[t] = (bf16_t)v[8 + t];
+                    p0[t] = EPI == VITMI_EPI_GELU_D ? deriv_pack(w[t], bf16_t()) : (bf16_t)w[t];
+                    p1[t] = EPI == VITMI_EPI_GELU_D ? deriv_pack(w[8 + t], bf16_t()) : (bf16_t)w[8 + t];
                 }
                 *reinterpret_cast<bf16x8*>(a) = p0;
                 *reinterpret_cast<bf16x8*>(a + H2) = p1;
             } else {
 #pragma unroll
                 for (int t = 0; t < 16; ++t)
-                    if (col(t) < N) a[col(t) - n] = (bf16_t)v[t];
+                    if (col(t) < N)
+                        a[col(t) - n] = EPI == VITMI_EPI_GELU_D ? deriv_pack(w[t], bf16_t()) : (bf16_t)w[t];
             }
         }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) v[t] = gelu_fast(v[t]);
-    } else if (EPI == VITMI_EPI_DGELU) {
+    } else if (epi_is_auxmul(EPI)) {
         const bf16_t* a = e.aux + (long long)m * e.ldaux + n;
         if (full) {
             const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(a);
             const bf16x8 p1 = *reinterpret_cast<const bf16x8*>(a + H2);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                v[t] *= gelu_grad_fast((float)p0[t]);
-                v[8 + t] *= gelu_grad_fast((float)p1[t]);
+                v[t] *= (EPI == VITMI_EPI_MULAUX) ? deriv_unpack(p0[t]) : gelu_grad_fast((float)p0[t]);
+                v[8 + t] *= (EPI == VITMI_EPI_MULAUX) ? deriv_unpack(p1[t]) : gelu_grad_fast((float)p1[t]);
             }
         } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t)
-                if (col(t) < N) v[t] *= gelu_grad_fast((float)a[col(t) - n]);
+                if (col(t) < N)
+                    v[t] *= (EPI == VITMI_EPI_MULAUX) ? deriv_unpack(a[col(t) - n]) : gelu_grad_fast((float)a[col(t) - n]);
         }
     }
     if (e.res) {
@@ -228,8 +238,8 @@ __device__ __forceinline__ void epi_subtile_fast(const FastEpi& e, f32x4 (&acc)[
 #pragma unroll
         for (int t = 0; t < 4; ++t) b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const bf16_t* op = (EPI == VITMI_EPI_DGELU) ? e.aux : e.res;
-    const long long ldop = (EPI == VITMI_EPI_DGELU) ? e.ldaux : e.ldr;
+    const bf16_t* op = epi_is_auxmul(EPI) ? e.aux : e.res;
+    const long long ldop = epi_is_auxmul(EPI) ? e.ldaux : e.ldr;
     bf16x8 o[8][2];
     auto fetch = [&](int i) {
         const int m = min(mrow0 + 16 * i, M - 1);
@@ -251,27 +261,35 @@ __device__ __forceinline__ void epi_subtile_fast(const FastEpi& e, f32x4 (&acc)[
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[j][i][r] + b[j][r];
-        if (EPI == VITMI_EPI_GELU) {
-            if (e.aux && live) {
-                bf16x8 p0, p1;
+        if (epi_is_gelu(EPI)) {
+            bf16x8 p0, p1;
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
+            for (int t = 0; t < 8; ++t) {
+                if (EPI == VITMI_EPI_GELU_D) {
+                    float d0, d1;
+                    gelu_both_fast(v[t], v[t], d0);
+                    gelu_both_fast(v[8 + t], v[8 + t], d1);
+                    p0[t] = deriv_pack(d0, bf16_t());
+                    p1[t] = deriv_pack(d1, bf16_t());
+                } else {
                     p0[t] = (bf16_t)v[t];
                     p1[t] = (bf16_t)v[8 + t];
+                    v[t] = gelu_fast(v[t]);
+                    v[8 + t] = gelu_fast(v[8 + t]);
                 }
+            }
+            if (e.aux && live) {
                 bf16_t* a = e.aux + (long long)m * e.ldaux + n;
                 *reinterpret_cast<bf16x8*>(a) = p0;
                 *reinterpret_cast<bf16x8*>(a + 32) = p1;
             }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) v[t] = gelu_fast(v[t]);
         }
         if (HAS_OP) {
-            if (EPI == VITMI_EPI_DGELU) {
+            if (epi_is_auxmul(EPI)) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    v[t] *= gelu_grad_fast((float)o[i][0][t]);
-                    v[8 + t] *= gelu_grad_fast((float)o[i][1][t]);
+                    v[t] *= (EPI == VITMI_EPI_MULAUX) ? deriv_unpack(o[i][0][t]) : gelu_grad_fast((float)o[i][0][t]);
+                    v[8 + t] *= (EPI == VITMI_EPI_MULAUX) ? deriv_unpack(o[i][1][t]) : gelu_grad_fast((float)o[i][1][t]);
                 }
             } else {
 #pragma unroll
@@ -422,7 +440,7 @@ template <int EPI, typename OutT, bool CS>
 __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __restrict__ A, long long lda,
                                                              const bf16_t* __restrict__ B, long long ldb,
                                                              FastEpi epi, int M, int N, int K, int tiles_n,
-                                                             int ntiles, int gm, int span, int xspan) {
+                                                             int ntiles, int gm, int span, int xspan, int stagger_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     const int lane = threadIdx.x & 63;
@@ -437,7 +455,7 @@ __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __res
     // chosen below one tile time), so the delay costs nothing.
     if (span > 0 || xspan > 0) {
         const int rem = ntiles % gridDim.x;
-        if (rem != 0 && (int)blockIdx.x >= rem) {
+        if (stagger_all || (rem != 0 && (int)blockIdx.x >= rem)) {
             const unsigned long long d =
                 (unsigned long long)((long long)span * (blockIdx.x >> 3) / 32 + (long long)xspan * (blockIdx.x & 7) / 8);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -624,9 +642,9 @@ __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __res
                           !(EPI != VITMI_EPI_NONE && epi.res);
     if (fast_epi) {
         const int mrow0 = m0 + wr * 128 + fr, nn = n0 + wc * 64 + 8 * fg;
-        if constexpr (EPI == VITMI_EPI_DGELU) {
+        if constexpr (epi_is_auxmul(EPI)) {
             epi_subtile_fast<EPI, CS, true>(epi, acc, mrow0, nn, M, cs);
-        } else if constexpr (EPI == VITMI_EPI_GELU) {
+        } else if constexpr (epi_is_gelu(EPI)) {
             epi_subtile_fast<EPI, CS, false>(epi, acc, mrow0, nn, M, cs);
         } else {
             if (epi.res)
@@ -1207,61 +1225,17 @@ static int phased_grid_blocks() {
     return c;
 }
 
-static int pick_nt_group(int N, int K);
-static int nt_span();
-static int nt_xspan();
-
-template <int EPI, typename OutT>
-static int launch_nt_phased(int M, int N, int K, const bf16_t* a, long long lda, const bf16_t* b, long long ldb,
-                            const FastEpi& e, hipStream_t s) {
-    static unsigned long long done = 0;
-    constexpr size_t lds = 2 * 4 * (size_t)RG * sizeof(bf16_t);
-    const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 256);
-    const int ntiles = tiles_m * tiles_n;
-    int grid = ntiles;
-    if (grid > phased_grid_blocks()) grid = phased_grid_blocks();
-    if (e.cs_partial) {
-        // column sums are produced by the one instantiation that needs them (dGELU -> bf16)
-        if (EPI != VITMI_EPI_DGELU || sizeof(OutT) != 2) {
-            vitmi_set_error("vitmi_gemm(nt phased): column sums are only fused into the dGELU epilogue");
-            return VITMI_ERR_BAD_ARG;
-        }
-        static unsigned long long done_cs = 0;
-        auto fcs = gemm_nt_phased_kernel<VITMI_EPI_DGELU, bf16_t, true>;
-        int rc = ensure_lds_attr(reinterpret_cast<const void*>(fcs), lds, &done_cs);
-        if (rc != VITMI_OK) return rc;
-        hipLaunchKernelGGL(fcs, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles,
-                           pick_nt_group(N, K), nt_span(), nt_xspan());
-        VITMI_LAUNCH_CHECK("vitmi_gemm(nt phased + column sums)");
-        return VITMI_OK;
-    }
-    auto fn = gemm_nt_phased_kernel<EPI, OutT, false>;
-    int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
-    if (rc != VITMI_OK) return rc;
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles,
-                       pick_nt_group(N, K), nt_span(), nt_xspan());
-    VITMI_LAUNCH_CHECK("vitmi_gemm(nt phased)");
-    return VITMI_OK;
-}
-
-// tile configuration: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves, 4x2), 2 = 256x256 (8 waves, 2x4),
-// 3 = 256x256 phased (K % 64 == 0, not for the patch operand)
-static int g_nt_cfg_override = -1;
-extern "C" int vitmi_debug_set_nt_config(int cfg) {
-    g_nt_cfg_override = cfg;
-    return VITMI_OK;
-}
-
 // row panels per group of the phased kernel's tile walk: -1 = automatic, 0 = n fastest
 static int g_nt_group_override = -1;
 extern "C" int vitmi_debug_set_nt_group(int gm) {
     g_nt_group_override = gm;
     return VITMI_OK;
 }
-static int g_nt_span = 0, g_nt_xspan = 0;
-extern "C" int vitmi_debug_set_nt_stagger(int span_ticks, int xspan_ticks) {
+static int g_nt_span = 0, g_nt_xspan = 0, g_nt_stagger_all = 0;
+extern "C" int vitmi_debug_set_nt_stagger(int span_ticks, int xspan_ticks, int all_blocks) {
     g_nt_span = span_ticks;
     g_nt_xspan = xspan_ticks;
+    g_nt_stagger_all = all_blocks;
     return VITMI_OK;
 }
 static int pick_nt_group(int N, int K) {
@@ -1274,8 +1248,46 @@ static int pick_nt_group(int N, int K) {
     return tiles_n >= 12 ? 12 : (tiles_n >= 6 ? 8 : 0);
 }
 
-static int nt_span() { return g_nt_span; }
-static int nt_xspan() { return g_nt_xspan; }
+template <int EPI, typename OutT>
+static int launch_nt_phased(int M, int N, int K, const bf16_t* a, long long lda, const bf16_t* b, long long ldb,
+                            const FastEpi& e, hipStream_t s) {
+    static unsigned long long done = 0;
+    constexpr size_t lds = 2 * 4 * (size_t)RG * sizeof(bf16_t);
+    const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 256);
+    const int ntiles = tiles_m * tiles_n;
+    int grid = ntiles;
+    if (grid > phased_grid_blocks()) grid = phased_grid_blocks();
+    if (e.cs_partial) {
+        // column sums are produced by the one instantiation that needs them (dGELU -> bf16)
+        if (!epi_is_auxmul(EPI) || sizeof(OutT) != 2) {
+            vitmi_set_error("vitmi_gemm(nt phased): column sums are only fused into the dGELU / aux-multiply epilogues");
+            return VITMI_ERR_BAD_ARG;
+        }
+        static unsigned long long done_cs = 0;
+        auto fcs = gemm_nt_phased_kernel<epi_is_auxmul(EPI) ? EPI : VITMI_EPI_DGELU, bf16_t, true>;
+        int rc = ensure_lds_attr(reinterpret_cast<const void*>(fcs), lds, &done_cs);
+        if (rc != VITMI_OK) return rc;
+        hipLaunchKernelGGL(fcs, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles,
+                           pick_nt_group(N, K), g_nt_span, g_nt_xspan, g_nt_stagger_all);
+        VITMI_LAUNCH_CHECK("vitmi_gemm(nt phased + column sums)");
+        return VITMI_OK;
+    }
+    auto fn = gemm_nt_phased_kernel<EPI, OutT, false>;
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(fn), lds, &done);
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a, lda, b, ldb, e, M, N, K, tiles_n, ntiles,
+                       pick_nt_group(N, K), g_nt_span, g_nt_xspan, g_nt_stagger_all);
+    VITMI_LAUNCH_CHECK("vitmi_gemm(nt phased)");
+    return VITMI_OK;
+}
+
+// tile configuration: 0 = 128x128 (4 waves), 1 = 256x128 (8 waves, 4x2), 2 = 256x256 (8 waves, 2x4),
+// 3 = 256x256 phased (K % 64 == 0, not for the patch operand)
+static int g_nt_cfg_override = -1;
+extern "C" int vitmi_debug_set_nt_config(int cfg) {
+    g_nt_cfg_override = cfg;
+    return VITMI_OK;
+}
 
 static int pick_nt_cfg(int M, int N) {
     if (g_nt_cfg_override >= 0) return g_nt_cfg_override;
@@ -1306,9 +1318,18 @@ static int launch_nt_fast(int M, int N, int K, const void* A, long long lda, con
     if (c_dt == VITMI_F32) return launch_nt_epi<VITMI_EPI_NONE, float, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
     if (epilogue == VITMI_EPI_NONE)
         return launch_nt_epi<VITMI_EPI_NONE, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
-    if (epilogue == VITMI_EPI_GELU)
-        return launch_nt_epi<VITMI_EPI_GELU, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
-    return launch_nt_epi<VITMI_EPI_DGELU, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+    if constexpr (PATCH) {
+        vitmi_set_error("patch embedding supports only the plain epilogue");
+        return VITMI_ERR_BAD_ARG;
+    } else {
+        if (epilogue == VITMI_EPI_GELU)
+            return launch_nt_epi<VITMI_EPI_GELU, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+        if (epilogue == VITMI_EPI_GELU_D)
+            return launch_nt_epi<VITMI_EPI_GELU_D, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+        if (epilogue == VITMI_EPI_MULAUX)
+            return launch_nt_epi<VITMI_EPI_MULAUX, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+        return launch_nt_epi<VITMI_EPI_DGELU, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+    }
 }
 
 // true when vitmi_gemm_nt_fast would run the phased kernel, the one that can also emit column sums;

@@ -9,7 +9,7 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import BF16, EPI_DGELU, EPI_GELU, EPI_NONE, F32, check, lib
+from ._lib import BF16, EPI_DGELU, EPI_GELU, EPI_GELU_D, EPI_MULAUX, EPI_NONE, F32, check, lib
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
@@ -824,7 +824,8 @@ class FFBlockFn(torch.autograd.Function):
             else:
                 g = mean = rstd = None
                 xn = x2
-            h, u = linear_fwd(xn, compute_copy(w1, cdt), b1.detach().float(), epi=EPI_GELU, want_aux=True)
+            # u = gelu'(pre-activation), evaluated in the forward epilogue beside gelu itself (same erf and exp)
+            h, u = linear_fwd(xn, compute_copy(w1, cdt), b1.detach().float(), epi=EPI_GELU_D, want_aux=True)
             if drop is None:
                 y, _ = linear_fwd(h, compute_copy(w2, cdt), b2.detach().float(), res=x2 if add_residual else None)
             else:
@@ -856,7 +857,7 @@ class FFBlockFn(torch.autograd.Function):
             dyd = dropout(dy2, drop[0], drop[2])
             dw2 = linear_bwd_w(dyd, h).to(w2.dtype)
             db2 = colsum(dyd).to(w2.dtype)
-            du = linear_bwd_x(dyd, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u, w_t=weight_t(w2, cdt))
+            du = linear_bwd_x(dyd, compute_copy(w2, cdt), epi=EPI_MULAUX, aux=u, w_t=weight_t(w2, cdt))
             dropout(du, drop[0], drop[1], out=du)
             dw1 = linear_bwd_w(du, xn).to(w1.dtype)
             db1 = colsum(du).to(w1.dtype)
@@ -875,7 +876,7 @@ class FFBlockFn(torch.autograd.Function):
             xn_ = xn if xn is not None else x2
             ps_weight(ps, dy2, h)
             ps_bias(ps, dy2)
-            du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u, w_t=weight_t(w2, cdt))
+            du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_MULAUX, aux=u, w_t=weight_t(w2, cdt))
             ps_weight(ps, du, xn_)
             ps_bias(ps, du)
             dxn = linear_bwd_x(du, compute_copy(w1, cdt), w_t=weight_t(w1, cdt))
@@ -915,7 +916,7 @@ class FFBlockFn(torch.autograd.Function):
         dw2 = linear_bwd_w(dy2, h).to(w2.dtype)
         fuse_db2 = has_ln and add_residual
         db2 = None if fuse_db2 else colsum(dy2).to(w2.dtype)
-        du, db1 = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_DGELU, aux=u, w_t=weight_t(w2, cdt),
+        du, db1 = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_MULAUX, aux=u, w_t=weight_t(w2, cdt),
                                want_colsum=True)
         dw1 = linear_bwd_w(du, xn).to(w1.dtype)
         db1 = db1.to(w1.dtype)
