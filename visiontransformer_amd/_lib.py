@@ -8,7 +8,8 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvitmi_hip.so")
+# VITMI_LIB: another build of the same library, for A/B timing of kernel versions on one box (tools/)
+LIB_PATH = os.environ.get("VITMI_LIB") or os.path.join(_HERE, "libvitmi_hip.so")
 
 F32, BF16 = 0, 1
 EPI_NONE, EPI_GELU, EPI_DGELU, EPI_GELU_D, EPI_MULAUX = 0, 1, 2, 3, 4
