@@ -56,29 +56,50 @@ def fwd_macs(kw, channels=3):
                                                            + 2 * N * D * M) + D * kw["num_classes"]
 
 
-def cpu_baseline(kw, masked, seconds_budget=20.0):
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(kw, masked, seconds_budget=14.0):
     """The CPU oracle (pure-torch restatement of the reference) on the host cores: a bounded
-    sample of the same workload -- batch 8, one warm-up step then timed steps."""
+    sample of the same workload -- batch 8, one warm-up step then timed steps -- with all the cores this
+    process may use and with one thread."""
     from oracle import vit_oracle
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
     B = 8
     params = vit_oracle.init_params(masked=masked, seed=1001, **kw)
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(B, 3, kw["image_size"], kw["image_size"], generator=g)
     y = torch.randint(0, kw["num_classes"], (B,), generator=g)
-    vit_oracle.loss_and_grads(params, x, y, kw["heads"])
-    t0 = time.perf_counter()
-    steps = 0
-    while steps < 3 or (time.perf_counter() - t0 < seconds_budget and steps < 8):
+
+    def timed(threads, budget, min_steps, max_steps):
+        torch.set_num_threads(threads)
         vit_oracle.loss_and_grads(params, x, y, kw["heads"])
-        steps += 1
-    dt = time.perf_counter() - t0
-    return {"value": B * steps / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle fwd+bwd fp32, batch {B}, {steps} timed steps after 1 warm-up"}
+        t0 = time.perf_counter()
+        steps = 0
+        while steps < min_steps or (time.perf_counter() - t0 < budget and steps < max_steps):
+            vit_oracle.loss_and_grads(params, x, y, kw["heads"])
+            steps += 1
+        return B * steps / (time.perf_counter() - t0), steps
+
+    many, steps = timed(cores, seconds_budget, 3, 8)
+    one, steps1 = timed(1, seconds_budget / 2, 1, 2)
+    torch.set_num_threads(cores)
+    return {"value": many, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd fp32, batch {B}, {steps} timed steps after 1 warm-up",
+            "one_thread": {"value": one, "unit": "images/s", "cores": 1,
+                           "sample": f"the same, {steps1} timed step(s) after 1 warm-up"},
+            "cpu_model": cpu_model_name(), "host_cpus": os.cpu_count()}
 
 
-PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
 # timer family -> substring of the kernel's name in the rocprofv3 counter summary
 PMC_KERNEL_OF_FAMILY = {
     "gemm_nt_phased_kernel|gemm_nt_fast_kernel[plain->bf16]": "gemm_nt_phased_kernelILi0EDF16b",
@@ -88,17 +109,22 @@ PMC_KERNEL_OF_FAMILY = {
 
 def pmc_traffic(family):
     """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC summary of this
-    same workload (counters cannot be read from inside the process): FETCH_SIZE x 2 + WRITE_SIZE."""
+    same workload (counters cannot be read from inside the process): FETCH_SIZE x 2 + WRITE_SIZE.  A summary
+    that does not hold the kernel is an error of the repository, not a silent null."""
     key = PMC_KERNEL_OF_FAMILY.get(family)
-    if key is None or not os.path.exists(PMC_TRAFFIC_FILE):
-        return {"traffic": None}
+    if key is None:
+        return {"traffic": None, "traffic_source": f"no counter pass recorded for {family}"}
+    if not os.path.exists(PMC_TRAFFIC_FILE):
+        raise SystemExit(f"bench.py: {PMC_TRAFFIC_FILE} is missing (the PMC summary roofline.traffic is read from)")
     with open(PMC_TRAFFIC_FILE) as f:
         kernels = json.load(f)["kernels"]
     for name, rec in kernels.items():
         if key in name:
             return {"traffic": rec["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
-                    "traffic_source": "profiles/r01e_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)"}
-    return {"traffic": None}
+                    "traffic_source": f"profiles/{os.path.basename(PMC_TRAFFIC_FILE)} (rocprofv3 --pmc FETCH_SIZE, "
+                                      "WRITE_SIZE in separate passes)"}
+    raise SystemExit(f"bench.py: no kernel matching {key!r} in {PMC_TRAFFIC_FILE}: the kernel was renamed, "
+                     "collect the counters again")
 
 
 def main():
@@ -167,7 +193,11 @@ def main():
     reducer = None
     if world > 1:
         broadcast_parameters(model, src=0)
-        reducer = GradReducer(model, bucket_mb=64, average=False)   # the 1/world factor rides on the Adam kernel
+        # the 1/world factor rides on the Adam kernel.  VITMI_BUCKET_DTYPE=bf16 halves the bytes on the links,
+        # VITMI_RESERVE_CUS=k keeps k compute units free of the persistent GEMMs for the collective's workgroups
+        reducer = GradReducer(model, bucket_mb=int(os.environ.get("VITMI_BUCKET_MB", "64")), average=False,
+                              dtype=torch.bfloat16 if os.environ.get("VITMI_BUCKET_DTYPE", "fp32") == "bf16"
+                              else torch.float32, reserve_cus=int(os.environ.get("VITMI_RESERVE_CUS", "0")))
     opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=5e-5)
 
     torch.manual_seed(1234 + rank)
@@ -317,6 +347,10 @@ def main():
             "train_gflop_per_image": gflop_img,
             "step_mfma_frac_per_gpu": step_tflops / MFMA_PEAK_TFLOPS,
             "final_loss": loss_val,
+            # what the data-parallel exchange was: ranks in the process group (RCCL when the backend is nccl),
+            # buckets and bytes per step
+            "exchange": (dict(reducer.info(), rccl_ranks=dist.get_world_size()
+                              if "nccl" in str(dist.get_backend()).lower() else 0) if reducer is not None else None),
             "roofline": roof,
             "cpu_baseline": cpu,
         }

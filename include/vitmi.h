@@ -133,6 +133,13 @@ int vitmi_debug_set_gelu_pair(int classic);
 /* same for the weight-gradient (tn) GEMM: 0 = 128x128, 1 = 256x256, -1 = automatic */
 int vitmi_debug_set_tn_config(int cfg);
 
+/* Leave k compute units (a multiple of 8 in [0, 128]; 0 = none, the default) free of the one-workgroup-per-CU GEMM
+ * kernels: the persistent nt kernel launches that many fewer blocks and the weight-gradient kernel sizes its token
+ * slabs for the smaller chip.  For data-parallel training, where a collective (RCCL) has to find compute units
+ * while the GEMMs of the backward pass hold the chip (DistributedDataParallel's overlap, trainer.py:184).
+ * Process-wide. */
+int vitmi_set_reserved_cus(int k);
+
 /* dst[c][r] (bf16) = src[r][c] (src_dt): the transposed bf16 compute copy of a weight, which
  * turns the input-gradient product dX = dY W into the k-contiguous form of vitmi_gemm.  No
  * reference counterpart (aten reads W through strides). */

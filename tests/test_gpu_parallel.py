@@ -14,26 +14,56 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_single_rank_rccl_step_runs_and_learns():
-    env = dict(os.environ, VITMI_DIST_BACKEND="nccl", REHEARSE_DEEP="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-u", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tools", "dist_rehearsal.py")]
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+def launch(script, nproc=1, **env):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **env)
+    cmd = [sys.executable, "-u", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", free_port(), os.path.join(ROOT, "tools", script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
-    out = r.stdout + r.stderr
-    assert r.returncode == 0, out[-3000:]
+    return r.returncode, r.stdout + r.stderr
+
+
+def test_single_rank_rccl_step_runs_and_learns():
+    rc, out = launch("dist_rehearsal.py", VITMI_DIST_BACKEND="nccl", REHEARSE_DEEP="1")
+    assert rc == 0, out[-3000:]
     losses = [float(x) for x in re.findall(r"step \d+ loss ([0-9.]+)", out)]
     assert len(losses) == 3 and losses[-1] < losses[0], out[-2000:]
     assert "max parameter difference to rank 0: 0.000e+00" in out
 
 
+def test_single_rank_rccl_step_with_bf16_buckets_and_reserved_compute_units():
+    """The two switches for the multi-GPU run: gradients travel as bf16 (half the bytes on the links) and the
+    persistent GEMM kernels leave 16 compute units to the collective; one rank on RCCL, the step still learns."""
+    rc, out = launch("dist_rehearsal.py", VITMI_DIST_BACKEND="nccl", REHEARSE_DEEP="1", REHEARSE_BF16="1",
+                     REHEARSE_RESERVE_CUS="16")
+    assert rc == 0, out[-3000:]
+    assert "'dtype': 'bfloat16'" in out and "'reserved_cus': 16" in out
+    losses = [float(x) for x in re.findall(r"step \d+ loss ([0-9.]+)", out)]
+    assert len(losses) == 3 and losses[-1] < losses[0], out[-2000:]
+
+
+def test_two_ranks_on_one_gpu_through_host_staged_gloo():
+    """Two processes drive the HIP modules on the one GPU and exchange gradients through gloo on host copies of the
+    buckets (no device tensor reaches gloo): the broadcast equalises the differently initialised replicas and three
+    averaged steps leave bit-identical parameters on both ranks."""
+    rc, out = launch("dist_rehearsal.py", nproc=2, VITMI_DIST_BACKEND="gloo")
+    assert rc == 0, out[-3000:]
+    assert out.count("max parameter difference to rank 0: 0.000e+00") == 2, out[-2000:]
+    l0 = re.findall(r"\[rank 0 [^\]]*\] step \d+ loss ([0-9.]+)", out)
+    l1 = re.findall(r"\[rank 1 [^\]]*\] step \d+ loss ([0-9.]+)", out)
+    assert len(l0) == 3 and len(l1) == 3 and l0 != l1          # different data per rank
+
+
 def test_torch_ddp_wraps_the_module_as_the_trainer_does():
     """trainer.py:184: DistributedDataParallel(model, find_unused_parameters=True) around ViT_mask.VIT, RCCL, one rank."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-u", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "tools", "ddp_wrap_check.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
-    out = r.stdout + r.stderr
-    assert r.returncode == 0 and "ddp wrap ok" in out, out[-3000:]
+    rc, out = launch("ddp_wrap_check.py")
+    assert rc == 0 and "ddp wrap ok" in out, out[-3000:]
 
 
 def test_data_parallel_wrapper_on_one_device():
@@ -59,10 +89,6 @@ def test_data_parallel_wrapper_on_one_device():
 def test_dpsgd_through_the_reducer_on_rccl():
     """Batched DP-SGD with the gradient reducer (sum over ranks, one noise draw, division by the global batch): one
     rank on RCCL gives bit for bit the gradient of the step without a reducer."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-u", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "tools", "dpsgd_dist_check.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
-    out = r.stdout + r.stderr
-    assert r.returncode == 0 and "dpsgd dist ok" in out, out[-3000:]
+    rc, out = launch("dpsgd_dist_check.py")
+    assert rc == 0 and "dpsgd dist ok" in out, out[-3000:]
     assert "with / without the reducer on one rank: 0.000e+00" in out

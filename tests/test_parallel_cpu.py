@@ -118,3 +118,75 @@ def test_reducer_ignores_undefined_gradient_arrivals():
         p.join(120)
         assert p.exitcode == 0
     assert out.get(timeout=5) is True
+
+
+def _worker_divergent(rank, world, port, out):
+    """Each rank's backward pass skips a DIFFERENT branch of the model, with buckets so small that every parameter
+    is its own collective: the ranks complete their buckets in different orders and leave different ones for
+    finish(), yet must issue the same sequence of collectives."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from visiontransformer_amd.parallel import GradReducer, broadcast_parameters
+    torch.manual_seed(3)
+    trunk = torch.nn.Linear(6, 6)
+    heads = torch.nn.ModuleList([torch.nn.Linear(6, 3), torch.nn.Linear(6, 3)])
+    model = torch.nn.ModuleList([trunk, heads])
+    broadcast_parameters(model, src=0)
+    red = GradReducer(model, bucket_mb=0.00001)
+    assert len(red.buckets) == 6
+    torch.manual_seed(11)
+    x_all = torch.randn(2, 4, 6)
+    ok = True
+    for step in range(2):
+        for p in model.parameters():
+            p.grad = None
+        heads[rank](torch.tanh(trunk(x_all[rank]))).pow(2).mean().backward()     # rank r uses head r only
+        red.finish()
+        # reference: the mean over ranks of each rank's own loss
+        ref = [torch.nn.Linear(6, 6), torch.nn.ModuleList([torch.nn.Linear(6, 3), torch.nn.Linear(6, 3)])]
+        ref = torch.nn.ModuleList(ref)
+        ref.load_state_dict(model.state_dict())
+        sum(ref[1][r](torch.tanh(ref[0](x_all[r]))).pow(2).mean() for r in range(world)).div(world).backward()
+        for p, q in zip(model.parameters(), ref.parameters()):
+            ok = ok and torch.allclose(p.grad, q.grad if q.grad is not None else torch.zeros_like(q), atol=1e-6)
+    # gradient accumulation: two local backward passes, one exchange
+    for p in model.parameters():
+        p.grad = None
+    with red.no_sync():
+        heads[0](torch.tanh(trunk(x_all[rank]))).sum().backward()
+    assert all(b.work is None for b in red.buckets)
+    heads[0](torch.tanh(trunk(x_all[rank]))).sum().backward()
+    red.finish()
+    ref.zero_grad()
+    sum(2 * ref[1][0](torch.tanh(ref[0](x_all[r]))).sum() for r in range(world)).div(world).backward()
+    ok = ok and torch.allclose(trunk.weight.grad, ref[0].weight.grad, atol=1e-5)
+    # bf16 buckets: the same exchange with half the bytes, within bf16 rounding
+    red.remove()
+    red16 = GradReducer(model, bucket_mb=0.00001, dtype=torch.bfloat16)
+    for p in model.parameters():
+        p.grad = None
+    heads[rank](torch.tanh(trunk(x_all[rank]))).pow(2).mean().backward()
+    red16.finish()
+    ref.zero_grad()
+    sum(ref[1][r](torch.tanh(ref[0](x_all[r]))).pow(2).mean() for r in range(world)).div(world).backward()
+    for p, q in zip(model.parameters(), ref.parameters()):
+        ok = ok and p.grad.dtype == torch.float32 and torch.allclose(p.grad, q.grad, atol=2e-2 * float(q.grad.abs().max()))
+    assert red16.info()["bucket_bytes"] == [2 * p.numel() for p in reversed(list(model.parameters()))]
+    if rank == 0:
+        out.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_unused_parameters_issue_the_same_collectives():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_divergent, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert out.get(timeout=5) is True

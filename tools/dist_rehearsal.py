@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Rehearsal of the data-parallel step with several ranks on ONE GPU (gloo backend, GPU tensors):
-every stage logs a line per rank.  Launch with torch.distributed.run --nproc-per-node 2.
-Observed on the MI355X box: the run completes (identical parameters on both ranks after three steps)
-or stalls inside one of gloo's GPU-tensor collectives (a broadcast or an all_reduce wait), at a
-different place from run to run -- gloo with two processes on one ROCm device is not dependable, so a
-stall here says nothing about the RCCL path; the watchdog prints where it stopped."""
+"""Rehearsal of the data-parallel step of the HIP modules: every stage logs a line per rank.  Launch with
+torch.distributed.run.  Backend "nccl" (RCCL; one rank per GPU) runs the collectives on device buffers; with
+"gloo" several ranks can share ONE GPU: broadcast_parameters and GradReducer then move the buckets through host
+copies (gloo's own device-tensor collectives stalled at varying places with two processes on one ROCm device, so
+nothing here hands gloo a device tensor).  REHEARSE_BF16=1 sends bf16 buckets, REHEARSE_RESERVE_CUS=k keeps k
+compute units free of the persistent GEMM kernels; the watchdog prints where a stalled run stopped."""
 import faulthandler
 import os
 import sys
@@ -26,19 +26,15 @@ torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 dist.init_process_group(os.environ.get("VITMI_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
 log("init ok")
-if os.environ.get("REHEARSE_BROADCAST_FIRST"):
-    b = torch.full((7,), float(rank + 1), device=dev)
-    dist.broadcast(b, src=0)
-    torch.cuda.synchronize()
-    log(f"broadcast as the first collective ok: {b[0].item()}")
-t = torch.full((1000,), float(rank + 1), device=dev)
+on_device = "nccl" in str(dist.get_backend()).lower()
+cdev = dev if on_device else torch.device("cpu")      # where this backend's collectives run
+t = torch.full((1000,), float(rank + 1), device=cdev)
 dist.all_reduce(t)
-torch.cuda.synchronize()
-log(f"sync all_reduce on a GPU tensor ok: {t[0].item()}")
 w = dist.all_reduce(t, async_op=True)
 w.wait()
-torch.cuda.synchronize()
-log("async all_reduce ok")
+if on_device:
+    torch.cuda.synchronize()
+log(f"plain all_reduce ok: {t[0].item()}")
 
 from visiontransformer_amd import ViT  # noqa: E402
 from visiontransformer_amd.optim import FusedAdam  # noqa: E402
@@ -53,7 +49,10 @@ else:
     m = ViT.VIT(32, 4, 64, 10, 2, 4, 128).to(dev).train()
 broadcast_parameters(m, src=0)
 log("broadcast ok")
-red = GradReducer(m, bucket_mb=float(os.environ.get("REHEARSE_BUCKET_MB", "0.05")))
+red = GradReducer(m, bucket_mb=float(os.environ.get("REHEARSE_BUCKET_MB", "0.05")),
+                  dtype=torch.bfloat16 if os.environ.get("REHEARSE_BF16") else torch.float32,
+                  reserve_cus=int(os.environ.get("REHEARSE_RESERVE_CUS", "0")))
+log(f"reducer: {red.info()}")
 if os.environ.get("REHEARSE_TRACE"):
     import threading
     _orig = dist.all_reduce
@@ -80,7 +79,7 @@ for step in range(3):
     torch.cuda.synchronize()
     log(f"step {step} loss {loss.item():.5f}")
 # all ranks must hold identical parameters after identical averaged updates
-flat = torch.cat([p.detach().flatten() for p in m.parameters()])
+flat = torch.cat([p.detach().flatten() for p in m.parameters()]).to(cdev)
 ref = flat.clone()
 dist.broadcast(ref, src=0)
 log(f"max parameter difference to rank 0: {(flat - ref).abs().max().item():.3e}")

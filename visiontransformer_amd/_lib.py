@@ -38,6 +38,7 @@ SIGNATURES = {
     "vitmi_transpose_cast": (I, [P, I, P, I, I, P]),
     "vitmi_debug_set_nt_config": (I, [I]),
     "vitmi_debug_set_tn_config": (I, [I]),
+    "vitmi_set_reserved_cus": (I, [I]),
     "vitmi_debug_set_nt_group": (I, [I]),
     "vitmi_debug_set_gelu_pair": (I, [I]),
     "vitmi_debug_set_nt_stagger": (I, [I, I, I]),
@@ -91,6 +92,8 @@ def _load():
             "(hipcc --offload-arch=gfx950).  This package has no other compute path.")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
+        if os.environ.get("VITMI_LIB") and not hasattr(lib, name):
+            continue             # an older build loaded for A/B timing may lack the newest entry points
         fn = getattr(lib, name)  # AttributeError here = header and library disagree
         fn.restype = res
         fn.argtypes = args

@@ -103,18 +103,38 @@ __device__ __forceinline__ void erf_exp_fast(float x, float& erf_v, float& e) {
     const float r = fmaf(-(p * t), e, 1.0f);
     erf_v = copysignf(r, x);
 }
+// GELU and its derivative for the bf16 epilogues through ONE exponential: Phi(x) ~ s(x) = 1 / (1 + exp(-x q(x^2))),
+// q an even polynomial fitted (minimax over [-8, 8] on x s(x) and on its derivative together) to the erf form;
+// |x s - gelu_erf(x)| <= 3.8e-5 and |(x s)' - gelu_erf'(x)| <= 9.3e-5, below half a unit in the last place of the
+// bf16 / half values they are rounded to.  17 issue slots for the pair instead of 26 with the erf evaluation above:
+// the epilogue of the first MLP GEMM is VALU-bound (16 values x 8 row groups per lane with the matrix pipes idle).
+// The polynomial's argument is clamped to [-8, 8], beyond which s is 0 or 1 to fp32 precision.
+__device__ __forceinline__ void gelu_sigmoid_parts(float x, float& s, float& e, float& xc, float& x2) {
+#pragma clang fp contract(off)
+    xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+    x2 = xc * xc;
+    // -log2(e) * {1.5948456719, 0.0740075325, -0.000694974849}
+    float q = fmaf(1.0026367671e-3f, x2, -1.0677030009e-1f);
+    q = fmaf(q, x2, -2.3008759357f);
+    e = __builtin_amdgcn_exp2f(xc * q);  // exp(-x q(x^2))
+    s = __builtin_amdgcn_rcpf(1.0f + e);
+}
 __device__ __forceinline__ float gelu_fast(float x) {
 #pragma clang fp contract(off)
-    float er, e;
-    erf_exp_fast(x, er, e);
-    return (0.5f * x) * (1.0f + er);
+    float s, e, xc, x2;
+    gelu_sigmoid_parts(x, s, e, xc, x2);
+    return x * s;
 }
 __device__ __forceinline__ void gelu_both_fast(float x, float& g, float& dg) {
 #pragma clang fp contract(off)
-    float er, e;
-    erf_exp_fast(x, er, e);
-    g = (0.5f * x) * (1.0f + er);
-    dg = fmaf(x * 0.39894228040143267794f, e, fmaf(0.5f, er, 0.5f));
+    float s, e, xc, x2;
+    gelu_sigmoid_parts(x, s, e, xc, x2);
+    // (x q(x^2))' = c0 + 3 c1 x^2 + 5 c2 x^4
+    float zp = fmaf(-3.4748742452e-3f, x2, 2.2202259742e-1f);
+    zp = fmaf(zp, x2, 1.5948456719f);
+    const float t = (s * (e * s)) * zp;  // s (1 - s) z'
+    g = x * s;
+    dg = fmaf(x, t, s);
 }
 __device__ __forceinline__ float gelu_grad_fast(float x) {
 #pragma clang fp contract(off)

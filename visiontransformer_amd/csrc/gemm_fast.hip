@@ -1210,19 +1210,31 @@ static int launch_nt_cfg(int M, int N, int K, const bf16_t* a, long long lda, co
     return VITMI_OK;
 }
 
+// Compute units the one-block-per-CU kernels leave free (for the workgroups of a collective that runs beside
+// them): a multiple of 8, so every XCD gives up the same number.
+static int g_reserved_cus = 0;
+extern "C" int vitmi_set_reserved_cus(int k) {
+    if (k < 0 || k > 128 || (k & 7)) {
+        vitmi_set_error("vitmi_set_reserved_cus: %d is not a multiple of 8 in [0, 128]", k);
+        return VITMI_ERR_BAD_ARG;
+    }
+    g_reserved_cus = k;
+    return VITMI_OK;
+}
+
 // persistent blocks of the phased nt kernel: one per CU, rounded down to a multiple of 8 so that a
-// block's tiles stay on its XCD
+// block's tiles stay on its XCD, minus the reserved ones
 static int phased_grid_blocks() {
     static int cached[64] = {0};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipGetDevice(&dev) != hipSuccess) return 256 - g_reserved_cus;
     int& c = cached[dev & 63];
     if (c == 0) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
         c = cus & ~7;
     }
-    return c;
+    return c - g_reserved_cus > 8 ? c - g_reserved_cus : 8;
 }
 
 // row panels per group of the phased kernel's tile walk: -1 = automatic, 0 = n fastest
@@ -1241,11 +1253,12 @@ extern "C" int vitmi_debug_set_nt_stagger(int span_ticks, int xspan_ticks, int a
 static int pick_nt_group(int N, int K) {
     if (g_nt_group_override >= 0) return g_nt_group_override;
     (void)K;
-    // measured at 50432 rows (tools/gemm_group_cmp.py): 12 column tiles (N = 3072, a 4.7 MB weight that does not fit
-    // one XCD's L2) 295 -> 250-260 us with groups of 12; 9 column tiles (N = 2304) 175 -> 166 us with groups of 8;
-    // three column tiles: no difference
+    // measured at 50432 rows (tools/gemm_group_cmp.py, tools/gemm_group_pmc.py): N = 3072 (12 column tiles, a 4.7 MB
+    // weight that does not fit one XCD's L2) plain 305 -> 243 us and FETCH_SIZE 485 -> 432 MB with groups of 8 (12:
+    // 241 us but 507 MB, 16: 587 MB: the group's A panels no longer fit); N = 2304 178 -> 171 us; three column
+    // tiles: no difference in time, more traffic
     const int tiles_n = ceil_div(N, 256);
-    return tiles_n >= 12 ? 12 : (tiles_n >= 6 ? 8 : 0);
+    return tiles_n >= 6 ? 8 : 0;
 }
 
 template <int EPI, typename OutT>
@@ -1384,7 +1397,7 @@ int vitmi_gemm_tn_slabs(int P, int Q, int T) {
     const int nk = ceil_div(T, TK);
     // blocks that are resident at once on 256 CUs; rounding DOWN keeps the launch to one round of
     // blocks (one block more than the chip holds would double the kernel's time)
-    const int target = cfg >= 1 ? 256 : 512;
+    const int target = (cfg >= 1 ? 1 : 2) * phased_grid_blocks();
     int s = target / tiles;
     if (s > nk) s = nk;
     if (s > 32) s = 32;
