@@ -190,6 +190,15 @@ long long vitmi_rollout_workspace_bytes(int L, int B, int N);
 int vitmi_rollout(const void* const* probs, int dt, int L, int B, int H, int N, int head_fusion, int discard_k,
                   int keep_first, int final_mode, float* out, void* workspace, void* stream);
 
+/* Gradient-weighted rollout (vit_grad_rollout.py:9-36) over L probability tensors and the L gradients that reached
+ * them (grads: HOST array of L device pointers, [B,H,N,N] dt each, layer order).  Per layer and sample: mean over the
+ * heads of probs * grads with negative means set to zero, the discard_k smallest entries zeroed, a = (A + I)/2 with
+ * entry (i, j) divided by the sum of ROW j (what `a / a.sum(dim=-1)` computes on the reference's batch of one), then
+ * row 0 of a_{L-1} ... a_0, columns 1..N-1, divided by its maximum.  The reference is defined for one image; every
+ * sample of a batch is treated here as that one image.  out: fp32 [B, N-1]; workspace as for vitmi_rollout. */
+int vitmi_grad_rollout(const void* const* probs, const void* const* grads, int dt, int L, int B, int H, int N,
+                       int discard_k, float* out, void* workspace, void* stream);
+
 /* out[b][j-1] = heads-fused probs[b, :, 0, j] for j = 1..N-1: last_attn of vit_rollout.py:64-73. fp32 [B, N-1]. */
 int vitmi_rollout_last_attn(const void* probs, int dt, int B, int H, int N, int head_fusion, float* out, void* stream);
 
@@ -260,9 +269,14 @@ int vitmi_layernorm_bwd_static(const void* dy, const void* x, long long ldx, con
  * reference hands to forward hooks on Attention.attend (ViT.py:100) / attn_drop. */
 int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, int B, int N, int H, int DH,
                    void* stream);
-/* dqkv from dout, recomputing the probabilities from qkv and lse.  dprobs ([B,H,N,N] dt,
- * gradient flowing into the exported probabilities) may be NULL. */
+/* dqkv from dout, recomputing the probabilities from qkv and lse.  dprobs ([B,H,N,N] dt, a gradient that reaches
+ * the exported probabilities from outside: a loss on the attention maps, the hooks of vit_grad_rollout.py:38-56) may
+ * be NULL; when given, its softmax backward (q and k slots) is added, the workspace must have
+ * vitmi_attn_bwd_dprobs_workspace_bytes, and dout (with out) may be NULL, in which case dqkv receives the dprobs share
+ * alone (v slots zero).  The dprobs share runs four small launches per (image, head): it serves attention-map
+ * analysis on a few images, not the training step. */
 long long vitmi_attn_bwd_workspace_bytes(int dt, int B, int N, int H, int DH);
+long long vitmi_attn_bwd_dprobs_workspace_bytes(int dt, int B, int N, int H, int DH);
 int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const void* dprobs,
                    void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, void* stream);
 

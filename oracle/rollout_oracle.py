@@ -12,7 +12,13 @@ Pinning: tests/golden/rollout.npz holds outputs of the reference's own function 
 trainer.py cannot be imported here (their top-level imports need torchvision / cv2), so tools/gen_golden.py
 parses the two files with `ast`, compiles ONLY the `rollout` / `last_attn` function definitions (pure torch)
 and runs those on seeded inputs.
+
+grad_rollout restates vit_grad_rollout.py:9-36 (gradient-weighted rollout; pinned the same way by
+tests/golden/grad_rollout.npz).  Its quirks, kept: the function is written for ONE image -- `flat[0, indices] = 0`
+discards in sample 0 only and `a / a.sum(dim=-1)` (no keepdim) divides entry (i, j) by the sum of row j; the result
+is a [w, w] numpy array divided by its maximum.
 """
+import numpy as np
 import torch
 
 
@@ -63,3 +69,24 @@ def trainer_rollout(attentions, discard_ratio=0.9, head_fusion="mean"):
 def last_attn(attentions, head_fusion):
     """vit_rollout.py:64-73."""
     return fuse(attentions[-1].float(), head_fusion)[:, 0, 1:]
+
+
+def grad_rollout(attentions, gradients, discard_ratio):
+    """vit_grad_rollout.py:9-36 for a batch of one -> numpy [w, w]."""
+    n = attentions[0].size(-1)
+    result = torch.eye(n)
+    for attention, grad in zip(attentions, gradients):
+        if attention.size(0) != 1:
+            raise ValueError("grad_rollout is defined for one image")
+        fused = (attention.float() * grad.float()).mean(axis=1).clone()
+        fused[fused < 0] = 0
+        flat = fused.view(1, -1)
+        _, indices = flat.topk(int(flat.size(-1) * discard_ratio), -1, False)
+        flat[0, indices] = 0
+        a = (fused + 1.0 * torch.eye(n)) / 2
+        a = a / a.sum(dim=-1)                 # [1,N,N] / [1,N]: column j divided by the sum of row j
+        result = torch.matmul(a, result)
+    mask = result[0, 0, 1:]
+    width = int(mask.size(-1) ** 0.5)
+    mask = mask.reshape(width, width).numpy()
+    return mask / np.max(mask)

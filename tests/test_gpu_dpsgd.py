@@ -55,7 +55,7 @@ def test_norms_and_clipped_sum_against_oracle(geom, dtype):
     loss, norms = dpsgd.clipped_noised_gradients(m, x.to(DEV), y.to(DEV), l2_norm_clip=CLIP, noise_multiplier=0.0)
     assert rel_err(norms, ref_norms) < TOL[dtype]
     worst = max((rel_err(p.grad, ref_grads[k]), k) for k, p in m.named_parameters())
-    assert worst[0] < 2 * TOL[dtype], worst
+    assert worst[0] < TOL[dtype], worst                   # measured worst: 2.2e-6 fp32, 1.1e-2 bf16
     # the literal schedule (B passes of one image) gives the same gradient
     m2 = ViT.VIT(**kw)
     m2.load_state_dict(params)
@@ -63,7 +63,7 @@ def test_norms_and_clipped_sum_against_oracle(geom, dtype):
     norms2 = dpsgd.literal_step_gradients(m2, x.to(DEV), y.to(DEV), l2_norm_clip=CLIP, noise_multiplier=0.0)
     assert rel_err(norms2, ref_norms) < TOL[dtype]
     worst = max((rel_err(p.grad, ref_grads[k]), k) for k, p in m2.named_parameters())
-    assert worst[0] < 2 * TOL[dtype], worst
+    assert worst[0] < TOL[dtype], worst
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -80,8 +80,15 @@ def test_timm_style_model_norms(dtype):
     _, norms = dpsgd.clipped_noised_gradients(m, x.to(DEV), y.to(DEV), l2_norm_clip=CLIP, noise_multiplier=0.0,
                                               unk_mask=None)
     assert rel_err(norms, ref_norms) < TOL[dtype]
-    worst = max((rel_err(p.grad, ref_grads[k]), k) for k, p in m.named_parameters())
-    assert worst[0] < 5 * TOL[dtype], worst
+    # Every tensor at the 1e-4 / 2e-2 bar but the LayerNorm weights in bf16: their clipped gradient is a sum over
+    # tokens of dy * xhat with heavy cancellation (max|ref| 1.9e-3 where the summands reach 1e-1), and with max|a-b| /
+    # max|b| as the measure one element of blocks.0.norm2.weight sits at 2.2e-2 (rms ratio 1.3e-2).  They get 3e-2
+    # on the maximum and the 2e-2 bar on the rms ratio.
+    for k, p in m.named_parameters():
+        loose = dtype == torch.bfloat16 and k.endswith(("norm1.weight", "norm2.weight"))
+        assert rel_err(p.grad, ref_grads[k]) < (3e-2 if loose else TOL[dtype]), k
+        d = (p.grad.detach().double().cpu() - ref_grads[k].double())
+        assert (d.pow(2).mean().sqrt() / ref_grads[k].double().pow(2).mean().sqrt()) < TOL[dtype], k
 
 
 def test_noise_statistics_and_reproducibility():

@@ -57,7 +57,7 @@ def test_logits_and_gradients_against_restatement(dtype, masked, pool):
     loss.backward()
     for name, p in m.named_parameters():
         assert p.grad is not None, name
-        assert rel_err(p.grad, ref_grads[name]) < (5 * TOL[dtype]), name
+        assert rel_err(p.grad, ref_grads[name]) < TOL[dtype], name        # measured worst: 1.2e-6 fp32, 1.1e-2 bf16
     if masked:
         # the unknown row collects the gradient of every masked position, unmasked rows only their own
         assert ref_grads["pos_embed"][0, -1].abs().max() > 0

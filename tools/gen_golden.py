@@ -133,6 +133,8 @@ def main():
         gen_jigsaw()
     if not only or "rollout" in only:
         gen_rollout()
+    if not only or "grad_rollout" in only:
+        gen_grad_rollout()
     if only:
         return
     # ---- mask vectors
@@ -230,6 +232,35 @@ def gen_rollout():
     path = os.path.join(OUT, "rollout.npz")
     np.savez_compressed(path, **arr)
     print("rollout", len(keys), "bytes", os.path.getsize(path))
+
+
+def gen_grad_rollout():
+    """vit_grad_rollout.grad_rollout (the function body alone; the file's imports need torchvision / cv2 / PIL) on
+    seeded probabilities and gradients of one image -> tests/golden/grad_rollout.npz."""
+    path = os.path.join(REF, "vit_grad_rollout.py")
+    import ast
+    tree = ast.parse(open(path).read(), filename=path)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "grad_rollout"]
+    ns = {"torch": torch, "np": np}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    ref = ns["grad_rollout"]
+    arr, keys = {}, []
+    for ci, (H, N, L) in enumerate([(3, 17, 3), (3, 65, 3), (2, 197, 2)]):
+        torch.manual_seed(700 + ci)
+        atts = [torch.softmax(2.0 * torch.randn(1, H, N, N), dim=-1) for _ in range(L)]
+        grads = [torch.randn(1, H, N, N) * 0.1 for _ in range(L)]
+        for l in range(L):
+            arr[f"c{ci}/att{l}"] = atts[l].numpy()
+            arr[f"c{ci}/grad{l}"] = grads[l].numpy()
+        arr[f"c{ci}/meta"] = np.array([H, N, L], dtype=np.int64)
+        for ratio in (0.9, 0.5, 0.0):
+            k = f"c{ci}/{ratio}"
+            keys.append(k)
+            arr[k + "/mask"] = ref([a.clone() for a in atts], [g.clone() for g in grads], ratio)
+    arr["keys"] = np.array(keys)
+    path = os.path.join(OUT, "grad_rollout.npz")
+    np.savez_compressed(path, **arr)
+    print("grad_rollout", len(keys), "bytes", os.path.getsize(path))
 
 
 if __name__ == "__main__":

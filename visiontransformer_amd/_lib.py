@@ -47,6 +47,7 @@ SIGNATURES = {
     "vitmi_patchify": (I, [P, I, P, I, I, I, I, I, I, P]),
     "vitmi_rollout_workspace_bytes": (L, [I, I, I]),
     "vitmi_rollout": (I, [P, I, I, I, I, I, I, I, I, I, P, P, P]),
+    "vitmi_grad_rollout": (I, [P, P, I, I, I, I, I, I, P, P, P]),
     "vitmi_rollout_last_attn": (I, [P, I, I, I, I, I, P, P]),
     "vitmi_ff_block_fwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P]),
     "vitmi_ff_block_bwd_workspace_bytes": (L, [I, I, I, I]),
@@ -75,6 +76,7 @@ SIGNATURES = {
     "vitmi_layernorm_bwd_static": (I, [P, P, L, P, P, P, P, P, P, P, P, I, L, I, P]),
     "vitmi_attn_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "vitmi_attn_bwd_workspace_bytes": (L, [I, I, I, I, I]),
+    "vitmi_attn_bwd_dprobs_workspace_bytes": (L, [I, I, I, I, I]),
     "vitmi_attn_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "vitmi_meanpool_fwd": (I, [P, P, I, I, I, I, P]),
     "vitmi_meanpool_bwd": (I, [P, P, I, I, I, I, P]),

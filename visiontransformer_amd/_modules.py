@@ -54,7 +54,29 @@ class ProbsTap(nn.Module):
     attn_drop (tim/models/vision_transformer.py:95-96, the module vit_rollout.py:85-87 hooks)."""
 
     def forward(self, probs):
-        return probs
+        # a view when gradients flow, so that backward hooks of either flavour see the gradient of THIS module's
+        # input (a hook on an output that is the input itself would be attached to the producer's node)
+        return probs.view_as(probs) if probs.requires_grad else probs
+
+
+def _has_backward_hooks(*mods):
+    return any(len(m._backward_hooks) + len(m._backward_pre_hooks) > 0 for m in mods)
+
+
+def attention_with_probability_gradients(mod, x, norm, w_qkv, b_qkv, proj, heads, taps, cdt):
+    """The attention sub-block as the chain LayerNorm -> to_qkv -> softmax(q k^T) -> [taps] -> probs @ v -> to_out of
+    separate autograd nodes, so that the gradient reaching the probabilities exists as a tensor and backward hooks
+    on the taps receive it (vit_grad_rollout.py:38-56).  Returns (y without residual, tapped probabilities)."""
+    if norm is not None:
+        x = ops.LayerNormFn.apply(x if x.dtype == cdt else _CastFn.apply(x, cdt), norm.weight, norm.bias, norm.eps)
+    qkv = ops.LinearFn.apply(x, w_qkv, b_qkv, cdt, None)
+    probs = ops.AttnProbsFn.apply(qkv, heads)
+    for t in taps:
+        probs = t(probs)
+    o = ops.ProbsApplyFn.apply(probs, qkv, heads)
+    if proj is not None:
+        o = ops.LinearFn.apply(o, proj.weight, proj.bias, cdt, None)
+    return o, probs
 
 
 class PatchEmbed(_HipModule):
@@ -150,6 +172,16 @@ class Attention(_HipModule):
         if x.dim() != 3:
             raise ValueError(f"Attention expects [batch, tokens, dim], got {tuple(x.shape)}")
         proj = self.to_out[0] if isinstance(self.to_out, nn.Sequential) else None
+        if torch.is_grad_enabled() and _has_backward_hooks(self.attend, self.attn_drop):
+            y, self.last_probs = attention_with_probability_gradients(
+                self, x, norm, self.to_qkv.weight, None, proj, self.heads, (self.attend, self.attn_drop),
+                self.compute_dtype)
+            p = self.to_out[1].p if proj is not None and self.training else 0.0
+            if p > 0:
+                y = ops.DropoutFn.apply(y, p, ops.new_seed())
+            if add_residual:
+                y = ops.AddFn.apply(y, x if x.dtype == y.dtype else _CastFn.apply(x, y.dtype))
+            return y
         want = self._export_wanted()
         # nn.Dropout after to_out (mymodel/ViT.py:90) sits between the projection and the residual add
         p = self.to_out[1].p if proj is not None and self.training else 0.0

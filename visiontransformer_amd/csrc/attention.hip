@@ -688,6 +688,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_f32_kernel(const float* __res
     }
 }
 
+// ================================================================ gradient arriving at the exported probabilities
+// One (image, head): dS[q][j] = P[q][j] * (dP[q][j] - sum_j' P[q][j'] dP[q][j']) * scale with P recomputed from the
+// fp32 scores S = q k^T and the row's log-sum-exp (softmax backward for a gradient dP that reaches the probabilities
+// from outside the fused kernel: a loss on the attention maps, gradient rollout).  One wave per query row.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_dprobs_rows_kernel(const float* __restrict__ S, const float* __restrict__ lse,
+                                                               const T* __restrict__ dP, T* __restrict__ dS, int N,
+                                                               float scale) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= N) return;
+    const float l = lse[q];
+    float dot = 0.f;
+    for (int j = lane; j < N; j += 64) dot += expf(S[(long long)q * N + j] * scale - l) * to_f32(dP[(long long)q * N + j]);
+    dot = wave_sum(dot);
+    for (int j = lane; j < N; j += 64) {
+        const float p = expf(S[(long long)q * N + j] * scale - l);
+        dS[(long long)q * N + j] = from_f32<T>(p * (to_f32(dP[(long long)q * N + j]) - dot) * scale);
+    }
+}
+
 // ---------------------------------------------------------------- dispatch helpers
 inline int pick_nc(int N) {
     const int need = (N + 31) / 32;
@@ -872,16 +893,61 @@ extern "C" long long vitmi_attn_bwd_workspace_bytes(int dt, int B, int N, int H,
     return 0;
 }
 
-extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const void* dprobs,
-                              void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, void* stream) {
-    VITMI_CHECK_ARG(qkv && out && dout && lse && dqkv, "vitmi_attn_bwd: null pointer");
-    int rc = check_common("vitmi_attn_bwd", dt, B, N, H, DH);
-    if (rc != VITMI_OK) return rc;
-    if (dprobs) {
-        vitmi_set_error("vitmi_attn_bwd: a gradient flowing into the exported probabilities is not supported");
-        return VITMI_ERR_UNSUPPORTED;
-    }
+static long long align256_ll(long long x) { return (x + 255) & ~255ll; }
+
+extern "C" long long vitmi_attn_bwd_dprobs_workspace_bytes(int dt, int B, int N, int H, int DH) {
+    if (B <= 0 || N <= 0 || H <= 0 || DH <= 0) return 0;
+    const long long es = dt == VITMI_F32 ? 4 : 2;
+    // the ordinary workspace, then: one head's fp32 scores, its dS, and a second [B,N,3*H*DH] gradient
+    return align256_ll(vitmi_attn_bwd_workspace_bytes(dt, B, N, H, DH)) + align256_ll((long long)N * N * 4) +
+           align256_ll((long long)N * N * es) + align256_ll((long long)B * N * 3 * H * DH * es);
+}
+
+// dst [B,N,3*H*DH] <- the share of dqkv that a gradient dprobs [B,H,N,N] on the probabilities contributes: its q and k
+// slots (the v slots are zeroed: v does not enter the probabilities).  Per (image, head): S = q k^T (fp32), the row
+// kernel above, dq = dS k, dk = dS^T q -- four launches through the generic GEMM; this path serves attention-map
+// analysis (gradient rollout on a handful of images), not the training step.
+static int attn_bwd_from_dprobs(const void* qkv, const float* lse, const void* dprobs, void* dst, float* S, void* dS,
+                                int dt, int B, int N, int H, int DH, void* stream) {
     hipStream_t s = as_stream(stream);
+    const long long es = dt == VITMI_F32 ? 4 : 2;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const float scale = 1.0f / sqrtf((float)DH);
+    hipError_t e = hipMemsetAsync(dst, 0, (size_t)((long long)B * N * ld * es), s);
+    if (e != hipSuccess) return vitmi_hip_fail(e, "vitmi_attn_bwd: hipMemsetAsync");
+    for (int b = 0; b < B; ++b)
+        for (int h = 0; h < H; ++h) {
+            const char* qb = (const char*)qkv + ((long long)b * N * ld + (long long)h * DH) * es;
+            const char* kb = qb + (long long)I * es;
+            char* dq = (char*)dst + ((long long)b * N * ld + (long long)h * DH) * es;
+            char* dk = dq + (long long)I * es;
+            const long long head = ((long long)b * H + h);
+            const char* dp = (const char*)dprobs + head * N * N * es;
+            int rc = vitmi_gemm(dt, N, N, DH, qb, ld, 1, kb, ld, 1, S, N, VITMI_F32, VITMI_EPI_NONE, nullptr, nullptr, 0,
+                                nullptr, 0, stream);
+            if (rc != VITMI_OK) return rc;
+            if (dt == VITMI_F32)
+                hipLaunchKernelGGL(attn_dprobs_rows_kernel<float>, dim3(ceil_div(N, 4)), dim3(256), 0, s, S, lse + head * N,
+                                   (const float*)dp, (float*)dS, N, scale);
+            else
+                hipLaunchKernelGGL(attn_dprobs_rows_kernel<bf16_t>, dim3(ceil_div(N, 4)), dim3(256), 0, s, S, lse + head * N,
+                                   (const bf16_t*)dp, (bf16_t*)dS, N, scale);
+            VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dprobs rows)");
+            // dq[q][d] = sum_j dS[q][j] k[j][d]
+            rc = vitmi_gemm(dt, N, DH, N, dS, N, 1, kb, 1, ld, dq, ld, dt, VITMI_EPI_NONE, nullptr, nullptr, 0, nullptr, 0,
+                            stream);
+            if (rc != VITMI_OK) return rc;
+            // dk[j][d] = sum_q dS[q][j] q[q][d]
+            rc = vitmi_gemm(dt, N, DH, N, dS, 1, N, qb, 1, ld, dk, ld, dt, VITMI_EPI_NONE, nullptr, nullptr, 0, nullptr, 0,
+                            stream);
+            if (rc != VITMI_OK) return rc;
+        }
+    return VITMI_OK;
+}
+
+static int attn_bwd_from_dout(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                              void* workspace, int dt, int B, int N, int H, int DH, hipStream_t s) {
     // five products of the flash-style backward: 10 * B * H * N^2 * DH
     ProfScope prof(VITMI_FAM_ATTN_BWD, s, 10.0 * B * H * (double)N * N * DH);
     if (dt == VITMI_F32) {
@@ -912,4 +978,27 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
         case 32: DISPATCH_NC(launch_bwd, 32, qkv, out, dout, lse, dqkv, B, N, H, s)
         default: DISPATCH_NC(launch_bwd, 64, qkv, out, dout, lse, dqkv, B, N, H, s)
     }
+}
+
+extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const void* dprobs,
+                              void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, void* stream) {
+    VITMI_CHECK_ARG(qkv && lse && dqkv, "vitmi_attn_bwd: null pointer");
+    VITMI_CHECK_ARG(dout || dprobs, "vitmi_attn_bwd: neither dout nor dprobs");
+    VITMI_CHECK_ARG(!dout || out, "vitmi_attn_bwd: dout needs out");
+    int rc = check_common("vitmi_attn_bwd", dt, B, N, H, DH);
+    if (rc != VITMI_OK) return rc;
+    hipStream_t s = as_stream(stream);
+    if (!dprobs) return attn_bwd_from_dout(qkv, out, dout, lse, dqkv, workspace, dt, B, N, H, DH, s);
+    VITMI_CHECK_ARG(workspace, "vitmi_attn_bwd: dprobs needs the workspace of vitmi_attn_bwd_dprobs_workspace_bytes");
+    const long long es = dt == VITMI_F32 ? 4 : 2;
+    char* w = (char*)workspace + align256_ll(vitmi_attn_bwd_workspace_bytes(dt, B, N, H, DH));
+    float* S = (float*)w;
+    void* dS = w + align256_ll((long long)N * N * 4);
+    void* tmp = (char*)dS + align256_ll((long long)N * N * es);
+    if (!dout) return attn_bwd_from_dprobs(qkv, lse, dprobs, dqkv, S, dS, dt, B, N, H, DH, stream);
+    rc = attn_bwd_from_dout(qkv, out, dout, lse, dqkv, workspace, dt, B, N, H, DH, s);
+    if (rc != VITMI_OK) return rc;
+    rc = attn_bwd_from_dprobs(qkv, lse, dprobs, tmp, S, dS, dt, B, N, H, DH, stream);
+    if (rc != VITMI_OK) return rc;
+    return vitmi_add(dqkv, tmp, dqkv, dt, (long long)B * N * 3 * H * DH, stream);
 }

@@ -13,8 +13,17 @@ namespace {
 
 constexpr int RL_THREADS = 1024;
 
+// fusion 0 mean, 1 max, 2 min over the heads; 3 = mean over the heads of probability x gradient with negative means
+// set to zero (vit_grad_rollout.py:14-16), g pointing at the gradient entry that matches p
 template <typename T>
-__device__ __forceinline__ float fuse_heads(const T* __restrict__ p, long long head_stride, int H, int fusion) {
+__device__ __forceinline__ float fuse_heads(const T* __restrict__ p, long long head_stride, int H, int fusion,
+                                            const T* __restrict__ g = nullptr) {
+    if (fusion == 3) {
+        float f = 0.f;
+        for (int h = 0; h < H; ++h) f += to_f32(p[h * head_stride]) * to_f32(g[h * head_stride]);
+        f = f / (float)H;
+        return f > 0.f ? f : 0.f;
+    }
     float f = to_f32(p[0]);
     if (fusion == 0) {
         for (int h = 1; h < H; ++h) f += to_f32(p[h * head_stride]);
@@ -63,8 +72,9 @@ __device__ __forceinline__ void hist_add(unsigned int* hist, unsigned bin, bool 
 constexpr int RL_REGVALS = 40;     // fused values a thread may hold in registers (REG path: N*N <= ~40 K, N <= 202)
 
 template <typename T, bool REG>
-__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void rollout_layer_kernel(LayerPtrs probs, int l0, float* __restrict__ a_all, int B,
-                                                                  int H, int N, int fusion, int k, int first) {
+__global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void rollout_layer_kernel(LayerPtrs probs, LayerPtrs grads, int l0, float* __restrict__ a_all, int B,
+                                                                  int H, int N, int fusion, int k, int first,
+                                                                  int norm_mode) {
     __shared__ unsigned int hist[256];
     __shared__ unsigned int sel[4];      // prefix, mask, remaining, count of the chosen bin
     __shared__ unsigned int wave_tot[RL_THREADS / WAVE];
@@ -73,6 +83,7 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const int lane = tid & (WAVE - 1), wave = tid / WAVE;
     const int NN = N * N;
     const T* p = reinterpret_cast<const T*>(probs.p[l]) + (long long)b * H * NN;
+    const T* gp = fusion == 3 ? reinterpret_cast<const T*>(grads.p[l]) + (long long)b * H * NN : nullptr;
     float* a = a_all + ((long long)(l0 + l) * B + b) * NN;
 
     // Head fusion reads 16 bytes per lane and head; N*N is odd for the usual token counts, so these runs are only
@@ -86,6 +97,23 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     float ftail = 0.f;
     auto fuse_run = [&](int g, float* out) {
         Run<T> run;
+        if (fusion == 3) {
+            Run<T> grun;
+#pragma unroll
+            for (int e = 0; e < V; ++e) out[e] = 0.f;
+            for (int h = 0; h < H; ++h) {
+                __builtin_memcpy(&run, p + (long long)h * NN + (long long)g * V, sizeof(run));
+                __builtin_memcpy(&grun, gp + (long long)h * NN + (long long)g * V, sizeof(grun));
+#pragma unroll
+                for (int e = 0; e < V; ++e) out[e] += to_f32(run.v[e]) * to_f32(grun.v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float m = out[e] / (float)H;
+                out[e] = m > 0.f ? m : 0.f;
+            }
+            return;
+        }
         __builtin_memcpy(&run, p + (long long)g * V, sizeof(run));
 #pragma unroll
         for (int e = 0; e < V; ++e) out[e] = to_f32(run.v[e]);
@@ -119,14 +147,15 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 for (int e = 0; e < V; ++e) f[r][e] = 0.f;
             }
         }
-        if (nvec * V + tid < NN) ftail = fuse_heads(p + nvec * V + tid, NN, H, fusion);
+        if (nvec * V + tid < NN) ftail = fuse_heads(p + nvec * V + tid, NN, H, fusion, gp ? gp + nvec * V + tid : nullptr);
     } else {
         for (int g = tid; g < nvec; g += RL_THREADS) {
             float t[V];
             fuse_run(g, t);
             store_run(g, t);
         }
-        for (int idx = nvec * V + tid; idx < NN; idx += RL_THREADS) a[idx] = fuse_heads(p + idx, NN, H, fusion);
+        for (int idx = nvec * V + tid; idx < NN; idx += RL_THREADS)
+            a[idx] = fuse_heads(p + idx, NN, H, fusion, gp ? gp + idx : nullptr);
         __syncthreads();
     }
     // fn(idx, bits, live) for every entry, called by whole waves (it votes)
@@ -245,17 +274,36 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     }
 
     // (A + I) / 2, each row divided by its sum: a wave per row
+    if (norm_mode == 0) {
+        for (int i = wave; i < N; i += RL_THREADS / WAVE) {
+            float* row = a + (long long)i * N;
+            float s = 0.f;
+            for (int j = lane; j < N; j += WAVE) s += (row[j] + (i == j ? 1.f : 0.f)) * 0.5f;
+            s = wave_sum(s);
+            for (int j = lane; j < N; j += WAVE) row[j] = (row[j] + (i == j ? 1.f : 0.f)) * 0.5f / s;
+        }
+        return;
+    }
+    // norm_mode 1, the arithmetic of vit_grad_rollout.py:27-28 on a batch of one: `a / a.sum(dim=-1)` without keepdim
+    // broadcasts the vector of row sums along the LAST axis, so entry (i, j) is divided by the sum of row j
+    __shared__ float rowsum[256];
     for (int i = wave; i < N; i += RL_THREADS / WAVE) {
-        float* row = a + (long long)i * N;
+        const float* row = a + (long long)i * N;
         float s = 0.f;
         for (int j = lane; j < N; j += WAVE) s += (row[j] + (i == j ? 1.f : 0.f)) * 0.5f;
         s = wave_sum(s);
-        for (int j = lane; j < N; j += WAVE) row[j] = (row[j] + (i == j ? 1.f : 0.f)) * 0.5f / s;
+        if (lane == 0) rowsum[i] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < NN; idx += RL_THREADS) {
+        const int i = idx / N, j = idx - i * N;
+        a[idx] = (a[idx] + (i == j ? 1.f : 0.f)) * 0.5f / rowsum[j];
     }
 }
 
 // Row 0 of a_{L-1} ... a_1 a_0 per sample, then the class-to-patch part [1:] in one of two final forms:
-// final_mode 0 = as is (trainer.py:44), 1 = divided by its maximum, then softmax (vit_rollout.py:51-55).
+// final_mode 0 = as is (trainer.py:44), 1 = divided by its maximum, then softmax (vit_rollout.py:51-55), 2 = divided by
+// its maximum (vit_grad_rollout.py:35).
 // v <- v a_l is split over CH_GROUPS groups of 256 threads (each a slice of the rows, four running sums per
 // thread so the loads stay in flight) and the partial vectors are added in a fixed order.
 constexpr int CH_GROUPS = 4;
@@ -314,6 +362,10 @@ __global__ __launch_bounds__(CH_THREADS) void rollout_chain_kernel(const float* 
     m = red[0];
     for (int q = 1; q < NW; ++q) m = fmaxf(m, red[q]);
     __syncthreads();
+    if (final_mode == 2) {
+        for (int j = 1 + tid; j < N; j += CH_THREADS) o[j - 1] = v[j] / m;
+        return;
+    }
     // softmax of t = v / m, whose maximum is 1 (m > 0 for any rollout of probabilities)
     float tmax = -INFINITY;
     for (int j = 1 + tid; j < N; j += CH_THREADS) tmax = fmaxf(tmax, v[j] / m);
@@ -354,29 +406,31 @@ extern "C" long long vitmi_rollout_workspace_bytes(int L, int B, int N) {
     return (long long)L * B * N * N * (long long)sizeof(float);
 }
 
-extern "C" int vitmi_rollout(const void* const* probs, int dt, int L, int B, int H, int N, int head_fusion,
-                             int discard_k, int keep_first, int final_mode, float* out, void* workspace, void* stream) {
-    VITMI_CHECK_ARG(probs && out && workspace, "vitmi_rollout: null pointer");
-    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_rollout: bad dtype %d", dt);
-    VITMI_CHECK_ARG(L > 0 && B > 0 && H > 0 && N > 1, "vitmi_rollout: bad geometry L=%d B=%d H=%d N=%d", L, B, H, N);
-    VITMI_CHECK_ARG(N <= 256, "vitmi_rollout: N=%d exceeds the supported 256 tokens", N);
-    VITMI_CHECK_ARG(head_fusion >= 0 && head_fusion <= 2, "vitmi_rollout: head_fusion %d (0 mean, 1 max, 2 min)",
-                    head_fusion);
-    VITMI_CHECK_ARG(discard_k >= 0 && discard_k <= N * N, "vitmi_rollout: discard_k %d outside [0, N*N]", discard_k);
-    VITMI_CHECK_ARG(final_mode == 0 || final_mode == 1, "vitmi_rollout: final_mode %d (0 raw, 1 max+softmax)", final_mode);
-    for (int l = 0; l < L; ++l) VITMI_CHECK_ARG(probs[l] != nullptr, "vitmi_rollout: probs[%d] is null", l);
+static int rollout_impl(const char* who, const void* const* probs, const void* const* grads, int dt, int L, int B, int H,
+                        int N, int head_fusion, int discard_k, int keep_first, int norm_mode, int final_mode, float* out,
+                        void* workspace, void* stream) {
+    VITMI_CHECK_ARG(probs && out && workspace, "%s: null pointer", who);
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "%s: bad dtype %d", who, dt);
+    VITMI_CHECK_ARG(L > 0 && B > 0 && H > 0 && N > 1, "%s: bad geometry L=%d B=%d H=%d N=%d", who, L, B, H, N);
+    VITMI_CHECK_ARG(N <= 256, "%s: N=%d exceeds the supported 256 tokens", who, N);
+    VITMI_CHECK_ARG(discard_k >= 0 && discard_k <= N * N, "%s: discard_k %d outside [0, N*N]", who, discard_k);
+    for (int l = 0; l < L; ++l)
+        VITMI_CHECK_ARG(probs[l] != nullptr && (!grads || grads[l] != nullptr), "%s: tensor %d is null", who, l);
     hipStream_t s = as_stream(stream);
     const int k = discard_k;
     float* a_all = (float*)workspace;
     const int es = dt == VITMI_F32 ? 4 : 2;
-    ProfScope prof(VITMI_FAM_OTHER, s, (double)L * B * N * N * ((double)H * es + 12.0));
+    ProfScope prof(VITMI_FAM_OTHER, s, (double)L * B * N * N * ((double)H * es * (grads ? 2 : 1) + 12.0));
     for (int l0 = 0; l0 < L; l0 += RL_MAXL) {
         const int nl = (L - l0) < RL_MAXL ? (L - l0) : RL_MAXL;
-        LayerPtrs tab;
-        for (int l = 0; l < RL_MAXL; ++l) tab.p[l] = l < nl ? probs[l0 + l] : nullptr;
+        LayerPtrs tab, gtab;
+        for (int l = 0; l < RL_MAXL; ++l) {
+            tab.p[l] = l < nl ? probs[l0 + l] : nullptr;
+            gtab.p[l] = (grads && l < nl) ? grads[l0 + l] : nullptr;
+        }
 #define RL_LAUNCH(T, REG)                                                                                             \
-    hipLaunchKernelGGL((rollout_layer_kernel<T, REG>), dim3(B, nl), dim3(RL_THREADS), 0, s, tab, l0, a_all, B, H, N,    \
-                       head_fusion, k, keep_first ? 1 : 0)
+    hipLaunchKernelGGL((rollout_layer_kernel<T, REG>), dim3(B, nl), dim3(RL_THREADS), 0, s, tab, gtab, l0, a_all, B, H, \
+                       N, head_fusion, k, keep_first ? 1 : 0, norm_mode)
         // registers hold the fused matrix when its 16-byte runs fit 40 values per thread (N <= 202) and there are
         // at least two runs per thread (below that most lanes would only vote)
         if (dt == VITMI_F32) {
@@ -392,8 +446,23 @@ extern "C" int vitmi_rollout(const void* const* probs, int dt, int L, int B, int
     }
     hipLaunchKernelGGL(rollout_chain_kernel, dim3(B), dim3(CH_THREADS), (2 + CH_GROUPS) * N * sizeof(float), s, a_all, out,
                        L, B, N, final_mode);
-    VITMI_LAUNCH_CHECK("vitmi_rollout");
+    VITMI_LAUNCH_CHECK(who);
     return VITMI_OK;
+}
+
+extern "C" int vitmi_rollout(const void* const* probs, int dt, int L, int B, int H, int N, int head_fusion,
+                             int discard_k, int keep_first, int final_mode, float* out, void* workspace, void* stream) {
+    VITMI_CHECK_ARG(head_fusion >= 0 && head_fusion <= 2, "vitmi_rollout: head_fusion %d (0 mean, 1 max, 2 min)",
+                    head_fusion);
+    VITMI_CHECK_ARG(final_mode == 0 || final_mode == 1, "vitmi_rollout: final_mode %d (0 raw, 1 max+softmax)", final_mode);
+    return rollout_impl("vitmi_rollout", probs, nullptr, dt, L, B, H, N, head_fusion, discard_k, keep_first, 0, final_mode,
+                        out, workspace, stream);
+}
+
+extern "C" int vitmi_grad_rollout(const void* const* probs, const void* const* grads, int dt, int L, int B, int H, int N,
+                                  int discard_k, float* out, void* workspace, void* stream) {
+    VITMI_CHECK_ARG(grads, "vitmi_grad_rollout: null pointer");
+    return rollout_impl("vitmi_grad_rollout", probs, grads, dt, L, B, H, N, 3, discard_k, 0, 1, 2, out, workspace, stream);
 }
 
 extern "C" int vitmi_rollout_last_attn(const void* probs, int dt, int B, int H, int N, int head_fusion, float* out,

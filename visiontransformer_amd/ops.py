@@ -271,6 +271,85 @@ def attn_bwd(qkv, out, dout, lse, B, N, H, DH):
     return dqkv
 
 
+def attn_bwd_dprobs(qkv, lse, dprobs, B, N, H, DH):
+    """The share of dqkv that a gradient on the exported probabilities contributes (q and k slots; v slots zero)."""
+    dprobs = dprobs.contiguous()
+    if dprobs.dtype != qkv.dtype:
+        dprobs = cast(dprobs, qkv.dtype)
+    dqkv = torch.empty_like(qkv)
+    ws = _ws(lib.vitmi_attn_bwd_dprobs_workspace_bytes(_dt(qkv), B, N, H, DH), qkv.device)
+    check(lib.vitmi_attn_bwd(_p(qkv), None, None, _p(lse), _p(dprobs), _p(dqkv), _p(ws), _dt(qkv), B, N, H, DH,
+                             _stream()), "vitmi_attn_bwd(dprobs)")
+    return dqkv
+
+
+class AttnProbsFn(torch.autograd.Function):
+    """qkv [B,N,3*H*DH] -> softmax(q k^T * scale) [B,H,N,N] as a differentiable tensor (mymodel/ViT.py:96-100): the
+    first half of the attention core when a caller wants the gradient that reaches the probabilities
+    (vit_grad_rollout.py:38-56 hooks attn_drop forwards AND backwards)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        _need_gpu(qkv)
+        qkv = qkv.contiguous()
+        B, N, I3 = qkv.shape
+        dh = I3 // 3 // heads
+        _, lse, probs = attn_fwd(qkv, B, N, heads, dh, True)
+        ctx.save_for_backward(qkv, lse)
+        ctx.geom = (B, N, heads, dh)
+        return probs
+
+    @staticmethod
+    def backward(ctx, dprobs):
+        qkv, lse = ctx.saved_tensors
+        B, N, H, dh = ctx.geom
+        return attn_bwd_dprobs(qkv, lse, dprobs, B, N, H, dh), None
+
+
+class ProbsApplyFn(torch.autograd.Function):
+    """(probs [B,H,N,N], qkv) -> probs @ v merged over heads, [B,N,H*DH] (mymodel/ViT.py:102-103): the second half.
+    One small GEMM per (image, head) through strided views, forwards and for each of the two gradients; meant for
+    attention-map analysis on a few images."""
+
+    @staticmethod
+    def forward(ctx, probs, qkv, heads):
+        _need_gpu(probs, qkv)
+        probs, qkv = probs.contiguous(), qkv.contiguous()
+        B, N, I3 = qkv.shape
+        I = I3 // 3
+        dh = I // heads
+        dt = _dt(qkv)
+        o = torch.empty((B, N, I), dtype=qkv.dtype, device=qkv.device)
+        for b in range(B):
+            for h in range(heads):
+                v = qkv[b, :, 2 * I + h * dh:]
+                gemm_raw(dt, N, dh, N, probs[b, h], N, 1, v, 1, I3, o[b, :, h * dh:], I, dt)
+        ctx.save_for_backward(probs, qkv)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        probs, qkv = ctx.saved_tensors
+        heads = ctx.heads
+        B, N, I3 = qkv.shape
+        I = I3 // 3
+        dh = I // heads
+        dt = _dt(qkv)
+        do = do.contiguous()
+        if do.dtype != qkv.dtype:
+            do = cast(do, qkv.dtype)
+        dprobs = torch.empty_like(probs)
+        dqkv = torch.zeros_like(qkv)
+        for b in range(B):
+            for h in range(heads):
+                v = qkv[b, :, 2 * I + h * dh:]
+                dob = do[b, :, h * dh:]
+                gemm_raw(dt, N, N, dh, dob, I, 1, v, I3, 1, dprobs[b, h], N, dt)                 # dP = dO V^T
+                gemm_raw(dt, N, dh, N, probs[b, h], 1, N, dob, 1, I, dqkv[b, :, 2 * I + h * dh:], I3, dt)   # dV = P^T dO
+        return dprobs, dqkv, None
+
+
 def add(a, b):
     y = torch.empty_like(a)
     check(lib.vitmi_add(_p(a), _p(b), _p(y), _dt(a), a.numel(), _stream()), "vitmi_add")

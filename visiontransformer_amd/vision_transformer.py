@@ -19,7 +19,8 @@ import torch
 from torch import nn
 
 from . import ops
-from ._modules import LayerNorm, Linear, PatchEmbed as _PatchEmbedBase, ProbsTap, _CastFn, _HipModule
+from ._modules import (LayerNorm, Linear, PatchEmbed as _PatchEmbedBase, ProbsTap, _CastFn, _HipModule,
+                       _has_backward_hooks, attention_with_probability_gradients)
 
 __all__ = ["Attention", "Mlp", "Block", "PatchEmbed", "VisionTransformer", "vit_small_patch16_224",
            "vit_base_patch16_224", "vit_tiny_patch16_224"]
@@ -62,11 +63,23 @@ class Attention(_HipModule):
         return self.fused_attn is False or len(self.attn_drop._forward_hooks) > 0
 
     def _run(self, x, norm, add_residual):
-        if self.attn_drop.p > 0 and self.training:
-            raise NotImplementedError("dropout on the attention probabilities (attn_drop > 0) is not implemented in "
-                                      "the HIP path")
-        want = self._export_wanted()
         p = self.proj_drop.p if self.training else 0.0       # proj_drop sits between the projection and the residual
+        drop_probs = self.attn_drop.p > 0 and self.training
+        if drop_probs or (torch.is_grad_enabled() and _has_backward_hooks(self.attn_drop)):
+            # dropout on the probabilities (tim/models/vision_transformer.py:95-96) and backward hooks on attn_drop
+            # (vit_grad_rollout.py:44-46) both need the probabilities as a tensor of the autograd graph
+            taps = (self.attn_drop,)
+            if drop_probs:
+                pd, seed = self.attn_drop.p, ops.new_seed()
+                taps = (lambda t: ops.DropoutFn.apply(t, pd, seed), self.attn_drop)
+            y, self.last_probs = attention_with_probability_gradients(
+                self, x, norm, self.qkv.weight, self.qkv.bias, self.proj, self.num_heads, taps, self.compute_dtype)
+            if p > 0:
+                y = ops.DropoutFn.apply(y, p, ops.new_seed())
+            if add_residual:
+                y = ops.AddFn.apply(y, x if x.dtype == y.dtype else _CastFn.apply(x, y.dtype))
+            return y
+        want = self._export_wanted()
         y, probs = ops.AttnBlockFn.apply(
             x, norm.weight if norm is not None else None, norm.bias if norm is not None else None,
             self.qkv.weight, self.proj.weight, self.proj.bias, self.num_heads,
