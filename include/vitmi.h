@@ -170,6 +170,12 @@ int vitmi_patchify(const void* x, int x_dt, void* out, int out_dt, int B, int C,
 int vitmi_jigsaw_gather(const void* x, void* out, int dt, int B, int C, int H, int W, int p, const int* src,
                         const void* bank, int bank_count, const int* bank_idx, const void* fill, void* stream);
 
+/* y[i] = min(max(x[i] * scale + addend[i], lo), hi): the whole-image branches of JigsawPuzzleMaskedRegion.__call__,
+ * "Scale" (masking_generator.py:210-213: x * scale, addend NULL, lo/hi infinite) and "noise" (:215-218: the host's
+ * N(0, 0.1) draw added, clipped to [0, 255]).  x, y in dt; addend fp32 [n] or NULL. */
+int vitmi_scale_add_clip(const void* x, const float* addend, void* y, int dt, long long n, float scale, float lo,
+                         float hi, void* stream);
+
 /* out[b,c,i,j] = (sum_t weight[t] * x[b, c, gy(t)*p+i, gx(t)*p+j]) / L over the L patches t of each image:
  * to_patches[:, :, seq_ord].mean(2) of the "repeat" branch (masking_generator.py:195-196) with weight[t] =
  * the number of times patch t occurs in seq_ord.  weight: fp32 [L] on the device; out: [B,C,p,p] in dt. */

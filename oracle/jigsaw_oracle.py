@@ -71,12 +71,23 @@ def apply(x, p, mask_type, flat, nonzero, shuffled, pub_data=None, pub_idx=None)
 
 def jigsaw(x, p, num_masking_patches, min_num_patches, mask_type, pub_data=None):
     """One JigsawPuzzleMaskedRegion.__call__: draws from the global RNG states, returns (images, masks);
-    masks is the [1, L+1] int32 array with the class-token pad, or None for "zero" / "repeat"."""
+    masks is the [1, L+1] int32 array with the class-token pad, or None for the branches that return none
+    (masking_generator.py:181-221).  "Scale" draws its factor from torch's CPU generator, "noise" its normal field
+    from numpy's; neither samples a mask, nor does an unknown mask_type (returned untouched)."""
+    if mask_type == "Scale":                                                # :210-213
+        import torch
+        scale = torch.rand(1) * (1.5 - 0.5) + 0.5
+        return (torch.from_numpy(x) * scale).numpy(), None
+    if mask_type == "noise":                                                # :215-218
+        noisy = x + np.random.normal(0, 0.1, np.shape(x)).astype(np.float32)
+        return np.clip(noisy, 0, 255), None
+    if mask_type not in ("mjp", "pbf", "orain", "zero", "repeat", "exchange"):
+        return x, None
     n, c, h, w = x.shape
     flat, nz, sh = masking_oracle.masked_indexes(h // p, w // p, num_masking_patches, min_num_patches)
     pub_idx = None
     if mask_type == "pbf":
         pub_idx = np.random.choice(np.arange(pub_data.shape[0]), n, replace=False).tolist()
-    out = apply(x, p, mask_type, flat, nz, sh, pub_data, pub_idx)
-    masks = None if mask_type in ("zero", "repeat") else masking_oracle.unk_mask_from_flat(flat)
+    out = apply(x, p, "mjp" if mask_type == "exchange" else mask_type, flat, nz, sh, pub_data, pub_idx)
+    masks = None if mask_type in ("zero", "repeat", "exchange") else masking_oracle.unk_mask_from_flat(flat)
     return out, masks

@@ -81,6 +81,7 @@ SIGNATURES = {
     "vitmi_meanpool_fwd": (I, [P, P, I, I, I, I, P]),
     "vitmi_meanpool_bwd": (I, [P, P, I, I, I, I, P]),
     "vitmi_add": (I, [P, P, P, I, L, P]),
+    "vitmi_scale_add_clip": (I, [P, P, P, I, L, F, F, F, P]),
     "vitmi_dropout": (I, [P, P, I, L, F, U64, P]),
     "vitmi_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, F, I, F, P]),
     "vitmi_adam_step_multi": (I, [P, I, P, I, I, F, F, F, F, F, I, F, P]),

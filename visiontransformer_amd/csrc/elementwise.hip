@@ -75,6 +75,19 @@ __global__ void add_kernel(const T* __restrict__ a, const T* __restrict__ b, T* 
     }
 }
 
+// y = clamp(x * scale + addend, lo, hi): the "Scale" and "noise" image augmentations (masking_generator.py:210-218)
+template <typename T>
+__global__ void scale_add_clip_kernel(const T* __restrict__ x, const float* __restrict__ addend, T* __restrict__ y,
+                                      long long n, float scale, float lo, float hi) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float v = to_f32(x[i]) * scale;
+        if (addend) v += addend[i];
+        y[i] = from_f32<T>(fminf(fmaxf(v, lo), hi));
+    }
+}
+
 // ---------------------------------------------------------------- column sums
 // stage 1: block (strip, chunk): partial[chunk][c] = sum over the chunk's rows; lane owns V
 // adjacent columns, the 4 waves of a block interleave rows and combine through LDS.
@@ -740,6 +753,26 @@ extern "C" int vitmi_cast(const void* src, int src_dt, void* dst, int dst_dt, lo
     if (src_dt == VITMI_BF16 && dst_dt == VITMI_BF16) return launch_cast<bf16_t, bf16_t>(src, dst, n, s);
     vitmi_set_error("vitmi_cast: unsupported dtype pair %d -> %d", src_dt, dst_dt);
     return VITMI_ERR_BAD_ARG;
+}
+
+extern "C" int vitmi_scale_add_clip(const void* x, const float* addend, void* y, int dt, long long n, float scale,
+                                    float lo, float hi, void* stream) {
+    VITMI_CHECK_ARG(x && y && n >= 0, "vitmi_scale_add_clip: bad argument");
+    if (n == 0) return VITMI_OK;
+    hipStream_t s = as_stream(stream);
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 8192);
+    if (dt == VITMI_F32)
+        hipLaunchKernelGGL(scale_add_clip_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x, addend, (float*)y,
+                           n, scale, lo, hi);
+    else if (dt == VITMI_BF16)
+        hipLaunchKernelGGL(scale_add_clip_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, addend,
+                           (bf16_t*)y, n, scale, lo, hi);
+    else {
+        vitmi_set_error("vitmi_scale_add_clip: bad dtype %d", dt);
+        return VITMI_ERR_BAD_ARG;
+    }
+    VITMI_LAUNCH_CHECK("vitmi_scale_add_clip");
+    return VITMI_OK;
 }
 
 extern "C" int vitmi_add(const void* a, const void* b, void* y, int dt, long long n, void* stream) {

@@ -106,19 +106,25 @@ class JigsawPuzzleMaskedRegion:
       "zero"   masked patches zeroed; returns (images, None)
       "repeat" masked patches <- mean over seq_ord of the image's patches (masked positions count patch 0,
                as the reference's arange*(1-mask) index does); returns (images, None)
+      "exchange" the "mjp" shuffle, returned as (images, None)
+    and the whole-image branches, which sample no mask (masking_generator.py:210-221):
+      "Scale"  images * s, s = torch.rand(1) * 1.0 + 0.5 from torch's CPU generator; (images, None)
+      "noise"  clip(images + N(0, 0.1), 0, 255), the normal draw taken from numpy's global generator on the host
+               exactly as the reference takes it, added and clipped by one launch; (images, None)
+      anything else: (images, None) untouched, like the reference's final else.
 
     pub_data is the unfolded public bank [P, C*p*p, L] that dataloader.public_data returns (dataloader.py:17-37).
     Decoding an image folder needs torchvision and is not part of this package: pass the bank as a tensor
-    (`pub_data=`); it is required for "pbf" only.  There is no CPU path: images must be device tensors.
+    (`pub_data=`), or, for "pbf" without it, the constructor calls the CALLER's own `dataloader.public_data(
+    pub_data_dir, ...)` (the module trainer.py:196-203 runs beside) and raises if there is none.  There is no CPU
+    path: images must be device tensors.
     """
 
-    MODES = ("mjp", "pbf", "orain", "zero", "repeat")
+    MODES = ("mjp", "pbf", "orain", "zero", "repeat", "exchange", "Scale", "noise")
 
     def __init__(self, img_size=224, patch_size=16, num_masking_patches=8, min_num_patches=2, mask_type="mjp",
                  pub_data_dir="../data/ImageNet100/public/", channels=3, device=None, pub_data=None):
         import torch
-        if mask_type not in self.MODES:
-            raise ValueError(f"mask_type {mask_type!r}: expected one of {self.MODES}")
         self.img_size, self.patch_size, self.channels = int(img_size), int(patch_size), int(channels)
         grid = int(img_size // patch_size)
         self.grid = grid
@@ -134,8 +140,14 @@ class JigsawPuzzleMaskedRegion:
         if pub_data is not None:
             self.set_public_data(pub_data)
         elif mask_type == "pbf":
-            raise ValueError("mask_type 'pbf' needs the public patch bank: pass pub_data=[P, C*p*p, L] (what "
-                             "dataloader.public_data returns); reading an image folder is outside this package")
+            try:                        # inside the reference tree: its loader (torchvision ImageFolder) builds the bank
+                from dataloader import public_data
+            except Exception as e:
+                raise ValueError("mask_type 'pbf' needs the public patch bank: pass pub_data=[P, C*p*p, L] (what "
+                                 "dataloader.public_data returns); no importable `dataloader.public_data` was found "
+                                 f"to build it from {pub_data_dir!r} ({type(e).__name__}: {e})") from None
+            self.set_public_data(public_data(root_dir=pub_data_dir, img_size=img_size, patch_size=patch_size,
+                                             channels=channels))
 
     def set_public_data(self, pub_data):
         """Keep the bank as the reference holds it (self.pub_data, [P, C*p*p, L]) and as [P, C, H, W] images, the
@@ -161,6 +173,15 @@ class JigsawPuzzleMaskedRegion:
         """x: [N, C, H, W] float32 or bfloat16 on the device.  Returns (images, masks) like the reference: masks is
         the [1, L+1] int32 numpy array with the class-token pad, or None for "zero" / "repeat"."""
         from . import ops
+        if self.mask_type == "Scale":                                       # masking_generator.py:210-213
+            import torch
+            scale = torch.rand(1) * (self.scale[1] - self.scale[0]) + self.scale[0]
+            return ops.scale_add_clip(x, scale=float(scale)), None
+        if self.mask_type == "noise":                                       # masking_generator.py:215-218
+            noise = np.random.normal(0, 0.1, tuple(x.shape)).astype(np.float32)
+            return ops.scale_add_clip(x, addend=ops.upload(noise, x.device), lo=0.0, hi=255.0), None
+        if self.mask_type not in ("mjp", "pbf", "orain", "zero", "repeat", "exchange"):
+            return x, None                                                  # the reference's final else
         flat, nz, sh = self._get_masked_indexes()
         masks = MaskingGenerator.unk_mask_from_flat(flat)
         if self.mask_type == "orain":
@@ -175,8 +196,10 @@ class JigsawPuzzleMaskedRegion:
         src[:] = np.arange(L, dtype=np.int32)
         table[L:] = 0
         bank = fill = None
-        if self.mask_type == "mjp":
+        if self.mask_type in ("mjp", "exchange"):
             src[nz] = sh
+            if self.mask_type == "exchange":
+                masks = None
         elif self.mask_type == "pbf":
             if self._bank is None:
                 raise ValueError("mask_type 'pbf' needs set_public_data() first")

@@ -356,6 +356,18 @@ def add(a, b):
     return y
 
 
+def scale_add_clip(x, scale=1.0, addend=None, lo=float("-inf"), hi=float("inf")):
+    """clamp(x * scale + addend, lo, hi) elementwise; addend fp32 of x's shape or None."""
+    _need_gpu(x, addend)
+    x = x.contiguous()
+    if addend is not None and (addend.dtype != torch.float32 or addend.numel() != x.numel() or not addend.is_contiguous()):
+        raise ValueError("addend must be a contiguous float32 tensor of x's size")
+    y = torch.empty_like(x)
+    check(lib.vitmi_scale_add_clip(_p(x), _p(addend), _p(y), _dt(x), x.numel(), float(scale), float(lo), float(hi),
+                                   _stream()), "vitmi_scale_add_clip")
+    return y
+
+
 def seq_ord(unk_mask, n, masked_row, device):
     """int64 [n]: i*(1-m[i]) + m[i]*masked_row from a 0/1 mask of n entries (any integer dtype / device)."""
     m = unk_mask.reshape(-1)
