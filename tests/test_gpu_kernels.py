@@ -436,3 +436,40 @@ def test_attention_long_sequences_bf16(N):
     assert rel_err(dqkv, ref_in.grad) < 2e-2
     with pytest.raises(RuntimeError, match="export"):
         ops.attn_fwd(qkv, B, N, H, DH, True)
+
+
+def test_fused_adam_groups_skipped_steps_and_type_checks():
+    """param_groups with their own learning rates (a scheduler writes group["lr"]), a parameter that skips a step
+    keeps torch.optim.Adam's per-parameter bias correction, and anything but contiguous float32 is refused instead
+    of being overwritten past its storage."""
+    from visiontransformer_amd.optim import FusedAdam
+    ref_p = [torch.nn.Parameter(rnd(33, 7, seed=60 + i)) for i in range(3)]
+    our_p = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+
+    def groups(ps):
+        return [{"params": ps[:2], "lr": 1e-2}, {"params": ps[2:], "lr": 1e-3, "weight_decay": 0.1}]
+
+    ref_opt = torch.optim.Adam(groups(ref_p), betas=(0.9, 0.99))
+    our_opt = FusedAdam(groups(our_p), betas=(0.9, 0.99))
+    assert [g["lr"] for g in our_opt.param_groups] == [1e-2, 1e-3]
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ref_p, our_p)):
+            if i == 1 and step == 1:            # this parameter takes no gradient at step 1
+                a.grad = b.grad = None
+                continue
+            g = rnd(33, 7, seed=200 + 10 * step + i)
+            a.grad, b.grad = g, g.to(DEV)
+        if step == 2:                           # what a scheduler does between epochs
+            ref_opt.param_groups[0]["lr"] = our_opt.param_groups[0]["lr"] = 5e-3
+        ref_opt.step()
+        our_opt.step()
+    for a, b in zip(ref_p, our_p):
+        assert rel_err(b, a.detach()) < 1e-6
+    half = torch.nn.Parameter(torch.zeros(8, 8, device=DEV, dtype=torch.bfloat16))
+    half.grad = torch.ones_like(half)
+    with pytest.raises(TypeError, match="contiguous float32"):
+        FusedAdam([half]).step()
+    strided = torch.nn.Parameter(torch.zeros(8, 8, device=DEV).t())
+    strided.grad = torch.ones(8, 8, device=DEV)
+    with pytest.raises(TypeError, match="contiguous float32"):
+        FusedAdam([strided]).step()

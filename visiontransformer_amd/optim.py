@@ -14,10 +14,30 @@ CHUNK = 65536  # elements per block
 
 
 class FusedAdam:
+    """params: an iterable of parameters or of {"params": [...], "lr": ..., ...} groups, as torch.optim.Adam takes
+    them.  `param_groups` is a list of dicts with the usual keys, so a torch LR scheduler written against
+    `optimizer.param_groups[i]["lr"]` drives it (trainer.py:206-211 steps CosineAnnealingLR; construct the scheduler
+    on a torch optimizer or set the entries yourself: this class does not derive from torch.optim.Optimizer).
+    Every parameter counts its own steps for the bias correction, as torch.optim.Adam does: one that skips a step
+    (grad None) is not advanced.  Parameters must be contiguous float32 device tensors: the kernel reads and writes
+    n fp32 elements at their address."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
-        self.params = [p for p in params if p.requires_grad]
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
-        self.step_count = 0
+        params = list(params)
+        groups = params if params and isinstance(params[0], dict) else [{"params": params}]
+        self.param_groups = []
+        for g in groups:
+            g = dict(g)
+            g["params"] = [p for p in g["params"] if p.requires_grad]
+            g.setdefault("lr", lr)
+            g.setdefault("betas", betas)
+            g.setdefault("eps", eps)
+            g.setdefault("weight_decay", weight_decay)
+            self.param_groups.append(g)
+        self.params = [p for g in self.param_groups for p in g["params"]]
+        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.step_count = 0          # calls of step()
+        self._steps = {}             # parameter -> updates it has taken
         self.state = {}
         self._tables = {}   # device -> (pinned host buffers, device buffer, copy-done events, parity)
         self._layouts = {}  # device -> (ids of the tensors, record constants, chunk table)
@@ -57,17 +77,34 @@ class FusedAdam:
         ent[3] = parity ^ 1
         return dev
 
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value):
+        for g in self.param_groups:
+            g["lr"] = value
+
     @torch.no_grad()
     def step(self, grad_scale=1.0):
         self.step_count += 1
-        by_device = {}
-        for p in self.params:
-            if p.grad is None:
-                continue
-            if not p.is_cuda:
-                raise RuntimeError("FusedAdam runs on ROCm device tensors only")
-            by_device.setdefault(p.device, []).append(p)
-        for device, plist in by_device.items():
+        launches = {}                # (device, group index, step number) -> parameters
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda:
+                    raise RuntimeError("FusedAdam runs on ROCm device tensors only")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError(f"FusedAdam updates contiguous float32 parameters in place; got {p.dtype}, "
+                                    f"contiguous={p.is_contiguous()}, shape {tuple(p.shape)} (keep fp32 master "
+                                    "weights: the compute dtype is set with set_compute_dtype, not .bfloat16())")
+                n = self._steps.get(p, 0) + 1
+                self._steps[p] = n
+                launches.setdefault((p.device, gi, n), []).append(p)
+        for (device, gi, nstep), plist in launches.items():
+            group = self.param_groups[gi]
             keep, g_ptr, p_ptr, p16_ptr, jobs = [], [], [], [], []
             for p in plist:
                 g = p.grad.contiguous()
@@ -84,7 +121,7 @@ class FusedAdam:
                     jobs.append((p.data_ptr(), hit_t.data_ptr(), p.shape[0], p.shape[1]))
                 else:
                     ops._cast_cache.pop((id(p), torch.bfloat16, "T"), None)
-            recs, chunks = self._layout(device, plist)
+            recs, chunks = self._layout((device, gi), plist)
             recs[:, 0] = p_ptr
             recs[:, 1] = g_ptr
             recs[:, 4] = p16_ptr
@@ -92,9 +129,9 @@ class FusedAdam:
             with torch.cuda.device(device):
                 dev = self._upload(device, words)
                 check(lib.vitmi_adam_step_multi(dev.data_ptr(), len(plist), dev.data_ptr() + 8 * recs.size,
-                                                chunks.size // 2, CHUNK, self.lr, self.betas[0], self.betas[1],
-                                                self.eps, self.weight_decay, self.step_count, grad_scale,
-                                                ops._stream()), "vitmi_adam_step_multi")
+                                                chunks.size // 2, CHUNK, group["lr"], group["betas"][0],
+                                                group["betas"][1], group["eps"], group["weight_decay"], nstep,
+                                                grad_scale, ops._stream()), "vitmi_adam_step_multi")
                 if jobs:
                     tiles = [((r + 63) // 64) * ((c + 63) // 64) for _, _, r, c in jobs]
                     starts = np.concatenate([[0], np.cumsum(tiles)[:-1]]).astype(np.int64)
