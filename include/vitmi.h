@@ -130,6 +130,9 @@ int vitmi_debug_set_nt_stagger(int span_ticks, int xspan_ticks, int all_blocks);
  * VITMI_EPI_DGELU.  Process-wide and to be left alone between a forward pass and its backward pass; for
  * benchmarking and error studies only. */
 int vitmi_debug_set_gelu_pair(int classic);
+/* 1 (default): when the persistent nt kernel's last round would fill less than half of the compute units, the
+ * rows of that round run as a second launch of the 128 x 128 kernel; 0: one launch.  Process-wide; benchmarking. */
+int vitmi_debug_set_nt_tail_split(int on);
 /* same for the weight-gradient (tn) GEMM: 0 = 128x128, 1 = 256x256, -1 = automatic */
 int vitmi_debug_set_tn_config(int cfg);
 

@@ -13,6 +13,8 @@ from visiontransformer_amd._lib import BF16, EPI_DGELU, EPI_GELU, EPI_GELU_D, EP
 T = 256 * 197
 bf = torch.bfloat16
 GMS = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "0,4,8,16").split(",")]
+if len(sys.argv) > 2:
+    lib.vitmi_debug_set_nt_tail_split(int(sys.argv[2]))
 
 
 def timed(fn, n=20):

@@ -1302,6 +1302,13 @@ extern "C" int vitmi_debug_set_nt_config(int cfg) {
     return VITMI_OK;
 }
 
+// rows of a thin last round on a second launch of the small-tile kernel: 1 = on
+static int g_nt_tail_split = 1;
+extern "C" int vitmi_debug_set_nt_tail_split(int on) {
+    g_nt_tail_split = on ? 1 : 0;
+    return VITMI_OK;
+}
+
 static int pick_nt_cfg(int M, int N) {
     if (g_nt_cfg_override >= 0) return g_nt_cfg_override;
     // measured on the ViT-B/16 shapes: 256x256 tiles win (1.2-1.3x over 128x128) once they fill the
@@ -1315,7 +1322,31 @@ static int launch_nt_epi(int M, int N, int K, const bf16_t* a, long long lda, co
                          const FastEpi& e, const PatchGeom& pg, hipStream_t s) {
     switch (pick_nt_cfg(M, N)) {
         case 3:
-            if (!PATCH && K % TK == 0 && K > 0) return launch_nt_phased<EPI, OutT>(M, N, K, a, lda, b, ldb, e, s);
+            if (!PATCH && K % TK == 0 && K > 0) {
+                // A last round that fills less than half of the chip costs a whole tile time on the persistent
+                // kernel (N = 768 at 50432 rows: 591 tiles = 2 rounds + 79).  The rows of that round go to a second
+                // launch of the 128 x 128 kernel instead: four times as many, smaller tiles, one or two per compute
+                // unit, no partial sums and no extra traffic.  Not with the fused column sums (only the persistent
+                // kernel produces them).
+                const int G = phased_grid_blocks();
+                const int tiles_m = ceil_div(M, 256), tiles_n = ceil_div(N, 256);
+                const long long ntiles = (long long)tiles_m * tiles_n;
+                const int rounds = (int)(ntiles / G), rem = (int)(ntiles % G);
+                const int head_panels = (int)(((long long)rounds * G) / tiles_n);
+                if (g_nt_tail_split && !e.cs_partial && e.rows_per_group == 0 && rounds >= 1 && rem > 0 && 2 * rem < G &&
+                    head_panels >= 1 && head_panels < tiles_m) {
+                    const int M1 = head_panels * 256;
+                    int rc = launch_nt_phased<EPI, OutT>(M1, N, K, a, lda, b, ldb, e, s);
+                    if (rc != VITMI_OK) return rc;
+                    FastEpi t = e;
+                    t.C = reinterpret_cast<OutT*>(e.C) + (long long)M1 * e.ldc;
+                    if (e.res) t.res = e.res + (long long)M1 * e.ldr;
+                    if (e.aux) t.aux = e.aux + (long long)M1 * e.ldaux;
+                    return launch_nt_cfg<EPI, OutT, PATCH, 128, 128, 2, 2>(M - M1, N, K, a + (long long)M1 * lda, lda, b, ldb,
+                                                                         t, pg, s);
+                }
+                return launch_nt_phased<EPI, OutT>(M, N, K, a, lda, b, ldb, e, s);
+            }
             [[fallthrough]];
         case 2: return launch_nt_cfg<EPI, OutT, PATCH, 256, 256, 2, 4>(M, N, K, a, lda, b, ldb, e, pg, s);
         case 1: return launch_nt_cfg<EPI, OutT, PATCH, 256, 128, 4, 2>(M, N, K, a, lda, b, ldb, e, pg, s);
