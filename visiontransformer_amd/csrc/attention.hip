@@ -8,8 +8,9 @@
 //             over that lane's registers plus two cross-lane steps, and the probability
 //             registers are directly the B operand of O^T = V^T P^T.  Key rows are fed to the
 //             first product in a permuted order chosen so that those registers come out in
-//             natural key order.  The same normalised bf16 probabilities feed P V and the
-//             optional export to HBM.
+//             natural key order.  The bf16-rounded exponentials feed P V and the result is scaled by
+//             1 / sum; the optional export to HBM writes the normalised probabilities, and the
+//             output is the same bit for bit with and without it.
 //   backward: two kernels that both recompute P from (Q, K, lse):
 //             dK/dV -- a wave owns 16 keys, sweeps all queries, accumulates dK^T, dV^T in
 //                      registers (S, dP computed with the KEY on the lane -> P, dS are B operands);
@@ -32,6 +33,35 @@ __device__ __forceinline__ bf16x8 zero8() {
 #pragma unroll
     for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.f;
     return z;
+}
+
+// Running maximum over the eight scores of one chunk in four v_max3_f32.  fmaxf would cost three times as many
+// instructions: MFMA results are not known to the compiler as quiet, so it copies each through a canonicalising
+// v_max first.  The compiler does not track MFMA-result hazards into inline assembly: callers finish every MFMA
+// that feeds these blocks first, fence with sched_barrier, and let the FIRST block spend the wait states.
+template <bool FIRST>
+__device__ __forceinline__ float max8_raw(float m, const f32x4& a, const f32x4& b) {
+    if (FIRST) asm volatile("s_nop 7\n\ts_nop 7");
+    asm volatile(
+        "v_max3_f32 %0, %0, %1, %2\n\t"
+        "v_max3_f32 %0, %0, %3, %4\n\t"
+        "v_max3_f32 %0, %0, %5, %6\n\t"
+        "v_max3_f32 %0, %0, %7, %8"
+        : "+v"(m)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+    return m;
+}
+// eight floats to a bf16 fragment, pairwise: four v_cvt_pk_bf16_f32, no byte shuffles
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+    union {
+        bf16x2 h[4];
+        bf16x8 v;
+    } u;
+    u.h[0] = __builtin_convertvector(f32x2{a[0], a[1]}, bf16x2);
+    u.h[1] = __builtin_convertvector(f32x2{a[2], a[3]}, bf16x2);
+    u.h[2] = __builtin_convertvector(f32x2{b[0], b[1]}, bf16x2);
+    u.h[3] = __builtin_convertvector(f32x2{b[2], b[3]}, bf16x2);
+    return u.v;
 }
 
 // permuted row -> sequence index inside a 32-wide chunk: the MFMA output register r of lane
@@ -138,9 +168,132 @@ __device__ __forceinline__ int xcd_block_order() {
 // elements of one wave's export tile buffer: 16 rows of N probabilities plus the alignment shift, in 16-byte units
 __host__ __device__ __forceinline__ int export_tile_elems(int N) { return (16 * N + 7 + 7) & ~7; }
 
+// One 16-query tile of the forward pass against the staged K and V images: scores, exact softmax, P V, the lse and
+// output rows, and (EXPORT) the probability tile.  qf holds the tile's query fragments.
+template <int DH, int NC, bool EXPORT>
+__device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs, const bf16x8 (&qf)[AttnDims<DH>::KS], int qt,
+                                              int b, int h, int N, int H, float scale, bf16_t* __restrict__ out,
+                                              float* __restrict__ lse, bf16_t* __restrict__ probs, bf16_t* Pw, int lane) {
+    using A = AttnDims<DH>;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int I = H * DH;
+    const int q = qt * 16 + fr;
+    const float sl2 = scale * LOG2E;
+    constexpr int nc_act = NC;                        // the launcher picks NC = ceil(N / 32): every chunk holds a real key
+    // S^T tiles: s[c][u][r] = score(query q, key 32c + 8fg + 4u + r)
+    f32x4 s[NC][2];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < nc_act) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const int krow = perm_row(c, u, fr);
+#pragma unroll
+                for (int ks = 0; ks < A::KS; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(Ks, krow, ks, fg), qf[ks], acc, 0, 0,
+                                                                  0);
+                s[c][u] = acc;
+            }
+            // up to 8 chunks NC = ceil(N / 32) and only the last chunk can reach past N; the long-sequence sizes
+            // (12, 16, 19 chunks) may hold several such chunks
+            if ((NC > 8 || c == NC - 1) && 32 * c + 32 > N) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (32 * c + 8 * fg + 4 * u + r >= N) s[c][u][r] = -INFINITY;
+            }
+            if (c & 1) __builtin_amdgcn_sched_barrier(0);   // keep the K fragment reads of later chunks from piling up in registers
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mx = max8_raw<true>(mx, s[0][0], s[0][1]);
+#pragma unroll
+    for (int c = 1; c < NC; ++c) mx = max8_raw<false>(mx, s[c][0], s[c][1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mb = mx * sl2;
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < nc_act) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[c][u][r], sl2, -mb));
+                    s[c][u][r] = p;
+                    sum += p;
+                }
+        }
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    if (fg == 0 && q < N) lse[((long long)b * H + h) * N + q] = mx * scale + __logf(sum);
+    // the tile's first element in the export tensor; the LDS copy starts at the same offset modulo 16 bytes,
+    // so that 16-byte pieces of the tile are aligned on both sides
+    bf16_t* gtile = EXPORT ? probs + (((long long)b * H + h) * N + qt * 16) * N : nullptr;
+    const int mis = EXPORT ? (int)((reinterpret_cast<uintptr_t>(gtile) >> 1) & 7) : 0;
+    bf16_t* ptile = Pw + mis;
+    // O^T = V^T P^T, d-tile by d-tile; V^T fragments come transposed out of the V row image
+    f32x4 o[A::DT];
+#pragma unroll
+    for (int dt = 0; dt < A::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c < nc_act) {
+            // the rounded exponentials feed P V and the 16 x DH result is scaled by 1 / sum afterwards (16 products
+            // per lane instead of one per score); the export rounds the normalised values on its own
+            const bf16x8 pf = pack8(s[c][0], s[c][1]);
+            if (EXPORT) {
+                const bf16x8 pn = pack8(s[c][0] * inv, s[c][1] * inv);
+                bf16_t* prow = ptile + fr * N + 32 * c + 8 * fg;
+                if (32 * c + 32 <= N) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) prow[j] = pn[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (32 * c + 8 * fg + j < N) prow[j] = pn[j];
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Vs, 32 * c, dt * 16, lane), pf, o[dt],
+                                                                0, 0, 0);
+            if (c & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (EXPORT) {
+        const int total = (N - qt * 16 < 16 ? N - qt * 16 : 16) * N;   // rows beyond N are left out
+        const int head = (8 - mis) & 7;                               // elements up to the first 16-byte boundary
+        if (lane < head && lane < total) gtile[lane] = ptile[lane];
+        const int pieces = total > head ? (total - head) >> 3 : 0;
+        for (int i = lane; i < pieces; i += 64)
+            *reinterpret_cast<bf16x8*>(gtile + head + 8 * i) = *reinterpret_cast<const bf16x8*>(ptile + head + 8 * i);
+        const int done = head + 8 * pieces;
+        if (done + lane < total) gtile[done + lane] = ptile[done + lane];
+    }
+    if (q < N) {
+        bf16_t* orow = out + ((long long)b * N + q) * I + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < A::DT; ++dt) {
+            const int d = dt * 16 + fg * 4;
+            if (d < DH) {
+                bf16x4 pk;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(o[dt][r] * inv);
+                *reinterpret_cast<bf16x4*>(orow + d) = pk;
+            }
+        }
+    }
+}
+
 // ================================================================ forward (bf16)
-// EXPORT is a template flag of the same kernel: the exported probabilities are the very bf16
-// values that feed P V.  Chunks of 32 keys that lie wholly beyond N are skipped, only the chunk
+// EXPORT is a template flag of the same kernel.  Chunks of 32 keys that lie wholly beyond N are skipped, only the chunk
 // that straddles N pays for the key mask; exponentials are raw v_exp_f32.
 template <int DH, int NC, bool EXPORT, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8 ? 4 : (NC <= 16 ? 2 : 1), NC <= 8 ? 4 : (NC <= 16 ? 2 : 1)))) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
@@ -169,8 +322,6 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8
     stage_img2<DH, NP, THREADS>(kb, ld, Ks, vb, ld, Vs, N);
     __syncthreads();
 
-    const float sl2 = scale * LOG2E;
-    constexpr int nc_act = NC;                        // the launcher picks NC = ceil(N / 32): every chunk holds a real key
     for (int qt = wave; qt * 16 < N; qt += nwaves) {
         const int q = qt * 16 + fr;
 #pragma unroll
@@ -178,114 +329,93 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8
             qf[ks] = qnext[ks];
             qnext[ks] = global_frag<DH>(qb, ld, q + nwaves * 16, N, ks, fg);
         }
-        // S^T tiles: s[c][u][r] = score(query q, key 32c + 8fg + 4u + r)
-        f32x4 s[NC][2];
-        float mx = -INFINITY;
+        attn_fwd_tile<DH, NC, EXPORT>(Ks, Vs, qf, qt, b, h, N, H, scale, out, lse, probs, Pw, lane);
+    }
+}
+
+// ================================================================ forward (bf16, heads of 64), streaming variant
+// One 16-wave workgroup per CU walks a contiguous range of (image, head) pairs.  T waves each own one 16-query tile
+// of the current pair; the other 16 - T waves do no arithmetic: while the tiles of pair i are computed they fetch
+// K and V of pair i + 1 into their (otherwise idle) registers and write the second pair of LDS images, so the HBM
+// round trip of the operands lies under the arithmetic of the pair before instead of in front of its own.  One
+// barrier per pair.  T = ceil(N / 16) <= 13.
+template <int T>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_stream_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H, float scale,
+    int npairs) {
+    constexpr int DH = 64;
+    constexpr int NC = (T + 1) / 2, NP = NC * 32, IMG = NP * DH;
+    constexpr int PT = (16 - T) * 64;                         // threads of the fetching waves
+    constexpr int IT = (T * 16 * 8 + PT - 1) / PT;            // 16-byte pieces of one matrix per fetching thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* img = reinterpret_cast<bf16_t*>(smem);            // [2 buffers][K, V][IMG]
+    const int ord = xcd_block_order();
+    const int p_begin = (int)((long long)ord * npairs / gridDim.x);
+    const int p_end = (int)((long long)(ord + 1) * npairs / gridDim.x);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+
+    // rows [16 T, NP) of the four images are never written again: zero them once
+    if constexpr (NP > 16 * T) {
+        constexpr int PAD = (NP - 16 * T) * 8;
+        for (int c = threadIdx.x; c < 4 * PAD; c += 1024) {
+            const int m = c / PAD, rem = c - m * PAD;
+            *reinterpret_cast<bf16x8*>(img + m * IMG + img_off<DH>(16 * T + (rem >> 3), rem & 7)) = zero8();
+        }
+    }
+    auto fetch = [&](int pair, bf16_t* kimg) {
+        const int b = pair / H, h = pair - b * H;
+        const bf16_t* kb = qkv + (long long)b * N * ld + I + h * DH;
+        int ptid = (int)threadIdx.x - T * 64;
+        asm volatile("" : "+v"(ptid));                        // addresses are recomputed per pair, not kept in registers
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (c < nc_act) {
+        for (int m = 0; m < 2; ++m) {                         // K, then V: one round trip each
+            const bf16_t* src = kb + m * I;
+            bf16_t* dst = kimg + m * IMG;
+            bf16x8 v[IT];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                    const int krow = perm_row(c, u, fr);
+            for (int i = 0; i < IT; ++i) {                    // rows past N re-read the last row; they are not written
+                const int j = ptid + i * PT, r = min(j >> 3, N - 1), kc = j & 7;
+                v[i] = *reinterpret_cast<const bf16x8*>(src + (long long)r * ld + kc * 8);
+            }
 #pragma unroll
-                    for (int ks = 0; ks < A::KS; ++ks)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(Ks, krow, ks, fg), qf[ks], acc, 0, 0,
-                                                                      0);
-                    s[c][u] = acc;
-                }
-                if (32 * c + 32 > N) {               // the one chunk that straddles N
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (32 * c + 8 * fg + 4 * u + r >= N) s[c][u][r] = -INFINITY;
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    mx = fmaxf(fmaxf(mx, fmaxf(s[c][u][0], s[c][u][1])), fmaxf(s[c][u][2], s[c][u][3]));
-                if (c & 1) __builtin_amdgcn_sched_barrier(0);   // keep the K fragment reads of later chunks from piling up in registers
+            for (int i = 0; i < IT; ++i) {                    // rows N .. 16 T - 1 are written as zeros
+                const int j = ptid + i * PT, r = j >> 3, kc = j & 7;
+                if (IT * PT == T * 128 || j < T * 128)
+                    *reinterpret_cast<bf16x8*>(dst + img_off<DH>(r, kc)) = r < N ? v[i] : zero8();
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mb = mx * sl2;
-        float sum = 0.f;
+    };
+    bf16x8 qf[2], qnext[2];
+    auto load_q = [&](int pair) {
+        const int b = pair / H, h = pair - b * H;
+        const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (c < nc_act) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(s[c][u][r], sl2, -mb));
-                        s[c][u][r] = p;
-                        sum += p;
-                    }
-            }
+        for (int ks = 0; ks < 2; ++ks) qnext[ks] = global_frag<DH>(qb, ld, wave * 16 + fr, N, ks, fg);
+    };
+    if (p_begin < p_end) {
+        if (wave >= T) fetch(p_begin, img);
+        else load_q(p_begin);
+    }
+    __syncthreads();
+    for (int pair = p_begin; pair < p_end; ++pair) {
+        const int cur = (pair - p_begin) & 1;
+        const bf16_t* Ks = img + cur * 2 * IMG;
+        if (wave >= T) {
+            if (pair + 1 < p_end) fetch(pair + 1, img + (cur ^ 1) * 2 * IMG);
+        } else {
+            qf[0] = qnext[0];
+            qf[1] = qnext[1];
+            if (pair + 1 < p_end) load_q(pair + 1);
+            const int b = pair / H, h = pair - b * H;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                      // likewise for the tile's offsets and key masks
+            attn_fwd_tile<DH, NC, false>(Ks, Ks + IMG, qf, wave, b, h, N, H, scale, out, lse, nullptr, nullptr, ln);
         }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        const float inv = __builtin_amdgcn_rcpf(sum);
-        if (fg == 0 && q < N) lse[((long long)b * H + h) * N + q] = mx * scale + __logf(sum);
-        // the tile's first element in the export tensor; the LDS copy starts at the same offset modulo 16 bytes,
-        // so that 16-byte pieces of the tile are aligned on both sides
-        bf16_t* gtile = EXPORT ? probs + (((long long)b * H + h) * N + qt * 16) * N : nullptr;
-        const int mis = EXPORT ? (int)((reinterpret_cast<uintptr_t>(gtile) >> 1) & 7) : 0;
-        bf16_t* ptile = Pw + mis;
-        // O^T = V^T P^T, d-tile by d-tile; V^T fragments come transposed out of the V row image
-        f32x4 o[A::DT];
-#pragma unroll
-        for (int dt = 0; dt < A::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            if (c < nc_act) {
-                bf16x8 pf;
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pf[4 * u + r] = (bf16_t)(s[c][u][r] * inv);
-                if (EXPORT) {
-                    bf16_t* prow = ptile + fr * N + 32 * c + 8 * fg;
-                    if (32 * c + 32 <= N) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) prow[j] = pf[j];
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            if (32 * c + 8 * fg + j < N) prow[j] = pf[j];
-                    }
-                }
-#pragma unroll
-                for (int dt = 0; dt < A::DT; ++dt)
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Vs, 32 * c, dt * 16, lane), pf, o[dt],
-                                                                    0, 0, 0);
-                if (c & 1) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (EXPORT) {
-            const int total = (N - qt * 16 < 16 ? N - qt * 16 : 16) * N;   // rows beyond N are left out
-            const int head = (8 - mis) & 7;                               // elements up to the first 16-byte boundary
-            if (lane < head && lane < total) gtile[lane] = ptile[lane];
-            const int pieces = total > head ? (total - head) >> 3 : 0;
-            for (int i = lane; i < pieces; i += 64)
-                *reinterpret_cast<bf16x8*>(gtile + head + 8 * i) = *reinterpret_cast<const bf16x8*>(ptile + head + 8 * i);
-            const int done = head + 8 * pieces;
-            if (done + lane < total) gtile[done + lane] = ptile[done + lane];
-        }
-        if (q < N) {
-            bf16_t* orow = out + ((long long)b * N + q) * I + h * DH;
-#pragma unroll
-            for (int dt = 0; dt < A::DT; ++dt) {
-                const int d = dt * 16 + fg * 4;
-                if (d < DH) {
-                    bf16x4 pk;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)o[dt][r];
-                    *reinterpret_cast<bf16x4*>(orow + d) = pk;
-                }
-            }
-        }
+        __syncthreads();
     }
 }
 
@@ -748,6 +878,36 @@ size_t fwd_smem() {
     return (size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t);
 }
 
+// compute units of the current device
+inline int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cached[dev & 63];
+    if (c == 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+        c = cus;
+    }
+    return c;
+}
+
+int g_attn_stream = 1;          // debug switch: 0 sends every shape to the one-workgroup-per-pair kernels
+
+template <int T>
+int launch_fwd_stream(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t s) {
+    constexpr int NC = (T + 1) / 2;
+    static unsigned long long done = 0;
+    const size_t sm = (size_t)4 * NC * 32 * 64 * sizeof(bf16_t);
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<T>), sm, &done, "vitmi_attn_fwd: LDS attribute");
+    if (rc != VITMI_OK) return rc;
+    const int grid = B * H < device_cus() ? B * H : device_cus();
+    hipLaunchKernelGGL((attn_fwd_stream_kernel<T>), dim3(grid), dim3(1024), sm, s, (const bf16_t*)qkv, (bf16_t*)out, lse,
+                       N, H, 0.125f, B * H);
+    VITMI_LAUNCH_CHECK("vitmi_attn_fwd(bf16, streaming)");
+    return VITMI_OK;
+}
+
 template <int DH, int NC, bool EXPORT, int THREADS>
 int launch_fwd_t(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
     const float scale = 1.0f / sqrtf((float)DH);
@@ -854,6 +1014,11 @@ int check_common(const char* who, int dt, int B, int N, int H, int DH) {
 
 }  // namespace
 
+extern "C" int vitmi_debug_set_attn_stream(int on) {
+    g_attn_stream = on;
+    return VITMI_OK;
+}
+
 extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, int B, int N, int H, int DH,
                               void* stream) {
     VITMI_CHECK_ARG(qkv && out && lse, "vitmi_attn_fwd: null pointer");
@@ -872,6 +1037,15 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* prob
         return VITMI_OK;
     }
     const int nc = pick_nc(N);
+    // heads of 64 without the export, 10..13 query tiles, at least four pairs per CU: the streaming kernel
+    if (g_attn_stream && DH == 64 && !probs && N > 144 && N <= 208 && B * H >= 4 * device_cus()) {
+        switch ((N + 15) / 16) {
+            case 10: return launch_fwd_stream<10>(qkv, out, lse, B, N, H, s);
+            case 11: return launch_fwd_stream<11>(qkv, out, lse, B, N, H, s);
+            case 12: return launch_fwd_stream<12>(qkv, out, lse, B, N, H, s);
+            default: return launch_fwd_stream<13>(qkv, out, lse, B, N, H, s);
+        }
+    }
     if (nc > 8) {
         if (probs) {
             vitmi_set_error("vitmi_attn_fwd: the probability export is limited to 256 tokens (N=%d)", N);
