@@ -133,10 +133,6 @@ int vitmi_debug_set_gelu_pair(int classic);
 /* 1 (default): when the persistent nt kernel's last round would fill less than half of the compute units, the
  * rows of that round run as a second launch of the 128 x 128 kernel; 0: one launch.  Process-wide; benchmarking. */
 int vitmi_debug_set_nt_tail_split(int on);
-/* 1 (default): bf16 attention over heads of 64 at 145..208 tokens runs the streaming kernels (one 16-wave workgroup
- * per compute unit, operands of the next (image, head) pair fetched under the arithmetic of the current one);
- * 0: one workgroup per pair for every shape.  Same results bit for bit.  Process-wide; benchmarking. */
-int vitmi_debug_set_attn_stream(int on);
 /* same for the weight-gradient (tn) GEMM: 0 = 128x128, 1 = 256x256, -1 = automatic */
 int vitmi_debug_set_tn_config(int cfg);
 
@@ -287,7 +283,9 @@ int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, 
  * be NULL; when given, its softmax backward (q and k slots) is added, the workspace must have
  * vitmi_attn_bwd_dprobs_workspace_bytes, and dout (with out) may be NULL, in which case dqkv receives the dprobs share
  * alone (v slots zero).  The dprobs share runs four small launches per (image, head): it serves attention-map
- * analysis on a few images, not the training step. */
+ * analysis on a few images, not the training step.  The dout path always needs the workspace of
+ * vitmi_attn_bwd_workspace_bytes (bf16: rowsum(dout * out) per query, [B,H,N] fp32, which the dQ kernel leaves for
+ * the dK/dV kernel; fp32: the probabilities and their gradient). */
 long long vitmi_attn_bwd_workspace_bytes(int dt, int B, int N, int H, int DH);
 long long vitmi_attn_bwd_dprobs_workspace_bytes(int dt, int B, int N, int H, int DH);
 int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const void* dprobs,

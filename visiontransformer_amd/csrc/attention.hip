@@ -20,6 +20,8 @@
 // fp32 kernels: one wave per query (or key) row, plain FMA; the parity path.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -61,6 +63,18 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
     u.h[1] = __builtin_convertvector(f32x2{a[2], a[3]}, bf16x2);
     u.h[2] = __builtin_convertvector(f32x2{b[0], b[1]}, bf16x2);
     u.h[3] = __builtin_convertvector(f32x2{b[2], b[3]}, bf16x2);
+    return u.v;
+}
+
+// the first n elements of a fragment, the others zeroed (whatever they held): n <= 0 clears it, n >= 8 keeps it
+__device__ __forceinline__ bf16x8 keep_first(const bf16x8& v, int n) {
+    union {
+        bf16x8 v;
+        u32x4 w;
+    } u;
+    u.v = v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u.w[i] &= (n > 2 * i ? 0xFFFFu : 0u) | (n > 2 * i + 1 ? 0xFFFF0000u : 0u);
     return u.v;
 }
 
@@ -216,6 +230,7 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float mb = mx * sl2;
     float sum = 0.f;
+    bf16x8 pfr[NC];                                   // without the export the exponentials are rounded as they appear
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         if (c < nc_act) {
@@ -227,6 +242,7 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
                     s[c][u][r] = p;
                     sum += p;
                 }
+            if (!EXPORT) pfr[c] = pack8(s[c][0], s[c][1]);
         }
     }
     sum += __shfl_xor(sum, 16, 64);
@@ -247,7 +263,7 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
         if (c < nc_act) {
             // the rounded exponentials feed P V and the 16 x DH result is scaled by 1 / sum afterwards (16 products
             // per lane instead of one per score); the export rounds the normalised values on its own
-            const bf16x8 pf = pack8(s[c][0], s[c][1]);
+            const bf16x8 pf = EXPORT ? pack8(s[c][0], s[c][1]) : pfr[c];
             if (EXPORT) {
                 const bf16x8 pn = pack8(s[c][0] * inv, s[c][1] * inv);
                 bf16_t* prow = ptile + fr * N + 32 * c + 8 * fg;
@@ -333,98 +349,12 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8
     }
 }
 
-// ================================================================ forward (bf16, heads of 64), streaming variant
-// One 16-wave workgroup per CU walks a contiguous range of (image, head) pairs.  T waves each own one 16-query tile
-// of the current pair; the other 16 - T waves do no arithmetic: while the tiles of pair i are computed they fetch
-// K and V of pair i + 1 into their (otherwise idle) registers and write the second pair of LDS images, so the HBM
-// round trip of the operands lies under the arithmetic of the pair before instead of in front of its own.  One
-// barrier per pair.  T = ceil(N / 16) <= 13.
-template <int T>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_fwd_stream_kernel(
-    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, float* __restrict__ lse, int N, int H, float scale,
-    int npairs) {
-    constexpr int DH = 64;
-    constexpr int NC = (T + 1) / 2, NP = NC * 32, IMG = NP * DH;
-    constexpr int PT = (16 - T) * 64;                         // threads of the fetching waves
-    constexpr int IT = (T * 16 * 8 + PT - 1) / PT;            // 16-byte pieces of one matrix per fetching thread
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* img = reinterpret_cast<bf16_t*>(smem);            // [2 buffers][K, V][IMG]
-    const int ord = xcd_block_order();
-    const int p_begin = (int)((long long)ord * npairs / gridDim.x);
-    const int p_end = (int)((long long)(ord + 1) * npairs / gridDim.x);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fr = lane & 15, fg = lane >> 4;
-    const int I = H * DH;
-    const long long ld = 3ll * I;
-
-    // rows [16 T, NP) of the four images are never written again: zero them once
-    if constexpr (NP > 16 * T) {
-        constexpr int PAD = (NP - 16 * T) * 8;
-        for (int c = threadIdx.x; c < 4 * PAD; c += 1024) {
-            const int m = c / PAD, rem = c - m * PAD;
-            *reinterpret_cast<bf16x8*>(img + m * IMG + img_off<DH>(16 * T + (rem >> 3), rem & 7)) = zero8();
-        }
-    }
-    auto fetch = [&](int pair, bf16_t* kimg) {
-        const int b = pair / H, h = pair - b * H;
-        const bf16_t* kb = qkv + (long long)b * N * ld + I + h * DH;
-        int ptid = (int)threadIdx.x - T * 64;
-        asm volatile("" : "+v"(ptid));                        // addresses are recomputed per pair, not kept in registers
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {                         // K, then V: one round trip each
-            const bf16_t* src = kb + m * I;
-            bf16_t* dst = kimg + m * IMG;
-            bf16x8 v[IT];
-#pragma unroll
-            for (int i = 0; i < IT; ++i) {                    // rows past N re-read the last row; they are not written
-                const int j = ptid + i * PT, r = min(j >> 3, N - 1), kc = j & 7;
-                v[i] = *reinterpret_cast<const bf16x8*>(src + (long long)r * ld + kc * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < IT; ++i) {                    // rows N .. 16 T - 1 are written as zeros
-                const int j = ptid + i * PT, r = j >> 3, kc = j & 7;
-                if (IT * PT == T * 128 || j < T * 128)
-                    *reinterpret_cast<bf16x8*>(dst + img_off<DH>(r, kc)) = r < N ? v[i] : zero8();
-            }
-        }
-    };
-    bf16x8 qf[2], qnext[2];
-    auto load_q = [&](int pair) {
-        const int b = pair / H, h = pair - b * H;
-        const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) qnext[ks] = global_frag<DH>(qb, ld, wave * 16 + fr, N, ks, fg);
-    };
-    if (p_begin < p_end) {
-        if (wave >= T) fetch(p_begin, img);
-        else load_q(p_begin);
-    }
-    __syncthreads();
-    for (int pair = p_begin; pair < p_end; ++pair) {
-        const int cur = (pair - p_begin) & 1;
-        const bf16_t* Ks = img + cur * 2 * IMG;
-        if (wave >= T) {
-            if (pair + 1 < p_end) fetch(pair + 1, img + (cur ^ 1) * 2 * IMG);
-        } else {
-            qf[0] = qnext[0];
-            qf[1] = qnext[1];
-            if (pair + 1 < p_end) load_q(pair + 1);
-            const int b = pair / H, h = pair - b * H;
-            int ln = lane;
-            asm volatile("" : "+v"(ln));                      // likewise for the tile's offsets and key masks
-            attn_fwd_tile<DH, NC, false>(Ks, Ks + IMG, qf, wave, b, h, N, H, scale, out, lse, nullptr, nullptr, ln);
-        }
-        __syncthreads();
-    }
-}
-
 // ================================================================ backward dK, dV (bf16)
 template <int DH, int NC>
 __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
-                                                                const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout,
                                                                 const float* __restrict__ lse,
+                                                                const float* __restrict__ delta_in,
                                                                 bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     using A = AttnDims<DH>;
     constexpr int NP = NC * 32;
@@ -441,24 +371,19 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
     const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
     const bf16_t* kb = qb + I;
     const bf16_t* vb = qb + 2 * I;
-    const bf16_t* ob = out + (long long)b * N * I + h * DH;
     const bf16_t* dob = dout + (long long)b * N * I + h * DH;
-    stage_img2<DH, NP>(qb, ld, Qs, dob, I, dOs, N);
-    // lse (in log2 units) and delta = rowsum(dO * O) per query; padded queries get p = 0
+    // lse (in log2 units) and delta = rowsum(dO * O) per query, the latter left by the dQ kernel; padded queries
+    // get p = 0
     for (int q = threadIdx.x; q < NP; q += blockDim.x) {
         float l2 = 1e30f, dl = 0.f;
         if (q < N) {
             l2 = lse[((long long)b * H + h) * N + q] * LOG2E;
-            for (int d = 0; d < DH; d += 8) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(ob + (long long)q * I + d);
-                const bf16x8 g = *reinterpret_cast<const bf16x8*>(dob + (long long)q * I + d);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dl += (float)a[j] * (float)g[j];
-            }
+            dl = delta_in[((long long)b * H + h) * N + q];
         }
         lse2[q] = l2;
         delta[q] = dl;
     }
+    stage_img2<DH, NP>(qb, ld, Qs, dob, I, dOs, N);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -496,7 +421,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -l2[r]));
                     pf[4 * u + r] = (bf16_t)p;
-                    dsf[4 * u + r] = (bf16_t)(p * (dpa[r] - dl[r]) * scale);
+                    dsf[4 * u + r] = (bf16_t)(p * (dpa[r] - dl[r]));     // the 1/sqrt(dh) goes onto the finished dK
                 }
             }
 #pragma unroll
@@ -517,7 +442,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
                     bf16x4 a, c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        a[r] = (bf16_t)dkt[dt][r];
+                        a[r] = (bf16_t)(dkt[dt][r] * scale);
                         c[r] = (bf16_t)dvt[dt][r];
                     }
                     *reinterpret_cast<bf16x4*>(dk + d) = a;
@@ -530,10 +455,11 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
 
 // ================================================================ backward dQ (bf16)
 template <int DH, int NC>
-__global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
+__global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8 ? 4 : 2, NC <= 8 ? 4 : 2))) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ out,
                                                                const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse,
+                                                               float* __restrict__ delta_out,
                                                                bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     using A = AttnDims<DH>;
     constexpr int NP = NC * 32;
@@ -582,7 +508,9 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dq_bf16_kernel(const bf
         }
         dl += __shfl_xor(dl, 16, 64);
         dl += __shfl_xor(dl, 32, 64);
-        const float l2 = q < N ? lsen * LOG2E : 1e30f;
+        if (fg == 0 && q < N) delta_out[((long long)b * H + h) * N + q] = dl;   // the dK, dV kernel reads it
+        // p * 1/sqrt(dh) comes straight out of the exponential: log2 of the factor joins the exponent
+        const float l2 = q < N ? lsen * LOG2E - __log2f(scale) : 1e30f;
         {
             const int q2 = q + nwaves * 16;
 #pragma unroll
@@ -597,8 +525,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dq_bf16_kernel(const bf
 #pragma unroll
         for (int dt = 0; dt < A::DT; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int c = 0; c < nc_act; ++c) {          // key chunks wholly beyond N contribute nothing
-            bf16x8 dsf;
+        for (int c = 0; c < nc_act; ++c) {
+            f32x4 ds[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int krow = perm_row(c, u, fr);
@@ -608,14 +536,12 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dq_bf16_kernel(const bf
                     sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(Ks, krow, ks, fg), qf[ks], sa, 0, 0, 0);
                     dpa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(Vs, krow, ks, fg), dof[ks], dpa, 0, 0, 0);
                 }
-                // this lane's rows are keys 32c + 8fg + 4u + r; padded keys contribute nothing
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -l2));
-                    if (32 * c + 32 > N && 32 * c + 8 * fg + 4 * u + r >= N) p = 0.f;   // straddling chunk only
-                    dsf[4 * u + r] = (bf16_t)(p * (dpa[r] - dl) * scale);
-                }
+                for (int r = 0; r < 4; ++r) ds[u][r] = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -l2)) * (dpa[r] - dl);
             }
+            // element j of the fragment is key 32c + 8fg + j
+            bf16x8 dsf = pack8(ds[0], ds[1]);
+            if (32 * c + 32 > N) dsf = keep_first(dsf, N - 32 * c - 8 * fg);   // keys past N contribute nothing
 #pragma unroll
             for (int dt = 0; dt < A::DT; ++dt)
                 dqt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Ks, 32 * c, dt * 16, lane), dsf, dqt[dt], 0,
@@ -878,36 +804,6 @@ size_t fwd_smem() {
     return (size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t);
 }
 
-// compute units of the current device
-inline int device_cus() {
-    static int cached[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256;
-    int& c = cached[dev & 63];
-    if (c == 0) {
-        int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-        c = cus;
-    }
-    return c;
-}
-
-int g_attn_stream = 1;          // debug switch: 0 sends every shape to the one-workgroup-per-pair kernels
-
-template <int T>
-int launch_fwd_stream(const void* qkv, void* out, float* lse, int B, int N, int H, hipStream_t s) {
-    constexpr int NC = (T + 1) / 2;
-    static unsigned long long done = 0;
-    const size_t sm = (size_t)4 * NC * 32 * 64 * sizeof(bf16_t);
-    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_stream_kernel<T>), sm, &done, "vitmi_attn_fwd: LDS attribute");
-    if (rc != VITMI_OK) return rc;
-    const int grid = B * H < device_cus() ? B * H : device_cus();
-    hipLaunchKernelGGL((attn_fwd_stream_kernel<T>), dim3(grid), dim3(1024), sm, s, (const bf16_t*)qkv, (bf16_t*)out, lse,
-                       N, H, 0.125f, B * H);
-    VITMI_LAUNCH_CHECK("vitmi_attn_fwd(bf16, streaming)");
-    return VITMI_OK;
-}
-
 template <int DH, int NC, bool EXPORT, int THREADS>
 int launch_fwd_t(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
     const float scale = 1.0f / sqrtf((float)DH);
@@ -951,8 +847,8 @@ int launch_fwd(const void* qkv, void* out, float* lse, void* probs, int B, int N
 }
 
 template <int DH, int NC>
-int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N, int H,
-               hipStream_t s) {
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+               int N, int H, hipStream_t s) {
     const float scale = 1.0f / sqrtf((float)DH);
     static unsigned long long done1 = 0, done2 = 0;
     const size_t s1 = dkv_smem<DH, NC>(), s2 = dq_smem<DH, NC>();
@@ -960,12 +856,13 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     if (rc != VITMI_OK) return rc;
     rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_dq_bf16_kernel<DH, NC>), s2, &done2, "vitmi_attn_bwd: LDS attribute (dq)");
     if (rc != VITMI_OK) return rc;
-    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DH, NC>), dim3(B * H), dim3(ATTN_THREADS), s1, s, (const bf16_t*)qkv,
-                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
-    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dkv, bf16)");
+    // dQ first: it leaves delta = rowsum(dO * O) per query in the workspace for the dK, dV kernel
     hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DH, NC>), dim3(B * H), dim3(ATTN_THREADS), s2, s, (const bf16_t*)qkv,
-                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, scale);
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
     VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dq, bf16)");
+    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DH, NC>), dim3(B * H), dim3(ATTN_THREADS), s1, s, (const bf16_t*)qkv,
+                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dkv, bf16)");
     return VITMI_OK;
 }
 
@@ -1014,11 +911,6 @@ int check_common(const char* who, int dt, int B, int N, int H, int DH) {
 
 }  // namespace
 
-extern "C" int vitmi_debug_set_attn_stream(int on) {
-    g_attn_stream = on;
-    return VITMI_OK;
-}
-
 extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, int B, int N, int H, int DH,
                               void* stream) {
     VITMI_CHECK_ARG(qkv && out && lse, "vitmi_attn_fwd: null pointer");
@@ -1037,15 +929,6 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* prob
         return VITMI_OK;
     }
     const int nc = pick_nc(N);
-    // heads of 64 without the export, 10..13 query tiles, at least four pairs per CU: the streaming kernel
-    if (g_attn_stream && DH == 64 && !probs && N > 144 && N <= 208 && B * H >= 4 * device_cus()) {
-        switch ((N + 15) / 16) {
-            case 10: return launch_fwd_stream<10>(qkv, out, lse, B, N, H, s);
-            case 11: return launch_fwd_stream<11>(qkv, out, lse, B, N, H, s);
-            case 12: return launch_fwd_stream<12>(qkv, out, lse, B, N, H, s);
-            default: return launch_fwd_stream<13>(qkv, out, lse, B, N, H, s);
-        }
-    }
     if (nc > 8) {
         if (probs) {
             vitmi_set_error("vitmi_attn_fwd: the probability export is limited to 256 tokens (N=%d)", N);
@@ -1064,7 +947,7 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* prob
 extern "C" long long vitmi_attn_bwd_workspace_bytes(int dt, int B, int N, int H, int DH) {
     (void)DH;
     if (dt == VITMI_F32) return 2ll * B * H * N * N * (long long)sizeof(float);
-    return 0;
+    return (long long)B * H * N * (long long)sizeof(float);     // delta = rowsum(dO * O) per query
 }
 
 static long long align256_ll(long long x) { return (x + 255) & ~255ll; }
@@ -1145,12 +1028,14 @@ static int attn_bwd_from_dout(const void* qkv, const void* out, const void* dout
         return VITMI_OK;
     }
     const int nc = pick_nc(N);
-    if (nc > 8) DISPATCH_NC_LONG(launch_bwd, qkv, out, dout, lse, dqkv, B, N, H, s)
+    VITMI_CHECK_ARG(workspace, "vitmi_attn_bwd: needs the workspace of vitmi_attn_bwd_workspace_bytes");
+    float* delta = (float*)workspace;               // [B, H, N] fp32
+    if (nc > 8) DISPATCH_NC_LONG(launch_bwd, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
     switch (DH) {
-        case 8: DISPATCH_NC(launch_bwd, 8, qkv, out, dout, lse, dqkv, B, N, H, s)
-        case 16: DISPATCH_NC(launch_bwd, 16, qkv, out, dout, lse, dqkv, B, N, H, s)
-        case 32: DISPATCH_NC(launch_bwd, 32, qkv, out, dout, lse, dqkv, B, N, H, s)
-        default: DISPATCH_NC(launch_bwd, 64, qkv, out, dout, lse, dqkv, B, N, H, s)
+        case 8: DISPATCH_NC(launch_bwd, 8, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
+        case 16: DISPATCH_NC(launch_bwd, 16, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
+        case 32: DISPATCH_NC(launch_bwd, 32, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
+        default: DISPATCH_NC(launch_bwd, 64, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
     }
 }
 
