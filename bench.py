@@ -100,31 +100,43 @@ def cpu_baseline(kw, masked, seconds_budget=14.0):
 
 
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-# timer family -> substring of the kernel's name in the rocprofv3 counter summary
-PMC_KERNEL_OF_FAMILY = {
-    "gemm_nt_phased_kernel|gemm_nt_fast_kernel[plain->bf16]": "gemm_nt_phased_kernelILi0EDF16b",
-    "gemm_tn_phased_kernel|gemm_tn_fast_kernel[+slab_reduce]": "gemm_tn_phased_kernel",
+# timer family -> substrings of the names, in the rocprofv3 counter summary, of the kernels one call of the family
+# launches: the first is the main kernel; a GEMM call also launches the small-tile kernel on the rows of a thin last
+# round (nt) or the slab reduction (tn)
+PMC_KERNELS_OF_FAMILY = {
+    "gemm_nt_phased_kernel|gemm_nt_fast_kernel[plain->bf16]": ["gemm_nt_phased_kernelILi0EDF16b",
+                                                               "gemm_nt_fast_kernelILi0EDF16bLb0ELi128ELi128"],
+    "gemm_tn_phased_kernel|gemm_tn_fast_kernel[+slab_reduce]": ["gemm_tn_phased_kernel", "slab_reduce_kernel"],
 }
 
 
 def pmc_traffic(family):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC summary of this
-    same workload (counters cannot be read from inside the process): FETCH_SIZE x 2 + WRITE_SIZE.  A summary
-    that does not hold the kernel is an error of the repository, not a silent null."""
-    key = PMC_KERNEL_OF_FAMILY.get(family)
-    if key is None:
+    """HBM bytes per call of the dominant kernel family, from the committed rocprofv3 PMC summary of this same
+    workload (counters cannot be read from inside the process): FETCH_SIZE x 2 + WRITE_SIZE, summed over the
+    kernels a call launches and divided by the launches of the main one.  A summary that does not hold the main
+    kernel is an error of the repository, not a silent null."""
+    keys = PMC_KERNELS_OF_FAMILY.get(family)
+    if keys is None:
         return {"traffic": None, "traffic_source": f"no counter pass recorded for {family}"}
     if not os.path.exists(PMC_TRAFFIC_FILE):
         raise SystemExit(f"bench.py: {PMC_TRAFFIC_FILE} is missing (the PMC summary roofline.traffic is read from)")
     with open(PMC_TRAFFIC_FILE) as f:
         kernels = json.load(f)["kernels"]
-    for name, rec in kernels.items():
-        if key in name:
-            return {"traffic": rec["hbm_bytes_per_launch"], "traffic_unit": "bytes/launch",
-                    "traffic_source": f"profiles/{os.path.basename(PMC_TRAFFIC_FILE)} (rocprofv3 --pmc FETCH_SIZE, "
-                                      "WRITE_SIZE in separate passes)"}
-    raise SystemExit(f"bench.py: no kernel matching {key!r} in {PMC_TRAFFIC_FILE}: the kernel was renamed, "
-                     "collect the counters again")
+    total, calls, parts = 0, 0, []
+    for i, key in enumerate(keys):
+        hits = [rec for name, rec in kernels.items() if key in name]
+        if not hits and i == 0:
+            raise SystemExit(f"bench.py: no kernel matching {key!r} in {PMC_TRAFFIC_FILE}: the kernel was renamed, "
+                             "collect the counters again")
+        for rec in hits:
+            total += rec["launches"] * rec["hbm_bytes_per_launch"]
+            parts.append(f"{key}: {rec['launches']} x {rec['hbm_bytes_per_launch']}")
+            if i == 0:
+                calls += rec["launches"]
+    return {"traffic": int(total / calls), "traffic_unit": "bytes/call",
+            "traffic_parts": parts,
+            "traffic_source": f"profiles/{os.path.basename(PMC_TRAFFIC_FILE)} (rocprofv3 --pmc FETCH_SIZE, "
+                              "WRITE_SIZE in separate passes)"}
 
 
 def main():
