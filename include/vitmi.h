@@ -133,6 +133,10 @@ int vitmi_debug_set_gelu_pair(int classic);
 /* 1 (default): when the persistent nt kernel's last round would fill less than half of the compute units, the
  * rows of that round run as a second launch of the 128 x 128 kernel; 0: one launch.  Process-wide; benchmarking. */
 int vitmi_debug_set_nt_tail_split(int on);
+/* 1 (default): bf16 attention over short sequences (<= 96 tokens) of narrow heads (<= 16 wide) gives a workgroup six
+ * adjacent heads of an image when the head count is a multiple of six; 0: one (image, head) pair per workgroup for
+ * every shape.  Same results bit for bit.  Process-wide; benchmarking. */
+int vitmi_debug_set_attn_head_groups(int on);
 /* same for the weight-gradient (tn) GEMM: 0 = 128x128, 1 = 256x256, -1 = automatic */
 int vitmi_debug_set_tn_config(int cfg);
 

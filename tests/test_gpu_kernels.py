@@ -246,6 +246,34 @@ def test_attention_spiky_scores(ops):
         assert abs(probs[0, 0, 7].float().sum().item() - 1.0) < 1e-2
 
 
+@pytest.mark.parametrize("B,N,H,DH", [(128, 65, 12, 8), (96, 33, 18, 16), (260, 17, 6, 8)])
+def test_attention_head_groups_bf16(ops, B, N, H, DH):
+    # short sequences of narrow heads with >= 256 groups of six heads: a workgroup takes six heads of an image
+    # (attn_*_kernel<.., HPW = 6>); against the fp32 expression and, bit for bit, against one pair per workgroup
+    from visiontransformer_amd._lib import lib
+    dtype = torch.bfloat16
+    qkv = rnd(B, N, 3 * H * DH, seed=5, scale=1.5)
+    do = rnd(B, N, H * DH, seed=6)
+    qr = q(qkv, dtype).requires_grad_(True)
+    o_ref, p_ref, lse_ref = attn_ref(qr, H, DH)
+    o_ref.backward(q(do, dtype))
+    qd = qkv.to(DEV, dtype)
+    got = {}
+    try:
+        for on in (1, 0):
+            lib.vitmi_debug_set_attn_head_groups(on)
+            o, lse, probs = ops.attn_fwd(qd, B, N, H, DH, True)
+            o2, _, _ = ops.attn_fwd(qd, B, N, H, DH, False)
+            dqkv = ops.attn_bwd(qd, o, do.to(DEV, dtype), lse, B, N, H, DH)
+            got[on] = (o, lse, probs, o2, dqkv)
+    finally:
+        lib.vitmi_debug_set_attn_head_groups(1)
+    o, lse, probs, o2, dqkv = got[1]
+    assert rel_err(o, o_ref) < TOL[dtype] and rel_err(probs, p_ref) < TOL[dtype] and rel_err(lse, lse_ref) < 1e-4
+    assert torch.equal(o, o2) and rel_err(dqkv, qr.grad) < TOL[dtype]
+    assert all(torch.equal(a, b) for a, b in zip(got[1], got[0]))
+
+
 def test_attention_rejects_long_sequences(ops):
     from visiontransformer_amd._lib import VitmiError
     with pytest.raises(VitmiError, match="not supported"):

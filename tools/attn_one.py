@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A few launches of the attention kernels on the ViT-B/16 shape, for profiler runs."""
+"""A few launches of the attention kernels, for profiler runs.  usage: attn_one.py [B N H DH] (default: the ViT-B/16 shape)"""
 import os
 import sys
 
@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from visiontransformer_amd import ops  # noqa: E402
 
-B, N, H, DH = 256, 197, 12, 64
+B, N, H, DH = [int(a) for a in sys.argv[1:5]] if len(sys.argv) >= 5 else (256, 197, 12, 64)
 qkv = torch.randn(B, N, 3 * H * DH, device="cuda").to(torch.bfloat16)
 do = torch.randn(B, N, H * DH, device="cuda").to(torch.bfloat16)
 for _ in range(5):

@@ -85,7 +85,7 @@ __device__ __forceinline__ int perm_row(int c, int u, int i) { return 32 * c + 8
 template <int DH> struct AttnDims {
     static constexpr int KS = DH >= 32 ? DH / 32 : 1;   // 32-wide k-steps over the head dim
     static constexpr int DT = DH >= 16 ? DH / 16 : 1;   // 16-wide output tiles over the head dim
-    static constexpr int W = DH >= 16 ? DH : 16;        // row width of an LDS image (a dh=8 row is zero-padded)
+    static constexpr int W = DH;                        // row width of an LDS image
     static constexpr int CPR = W / 8;                   // 16-byte chunks per image row
 };
 
@@ -95,7 +95,10 @@ template <int DH> struct AttnDims {
 // For 128-byte rows (dh = 64) chunk c of row r is stored at chunk c ^ swz(r) with
 // swz(r) = 2*bit1(r) | 4*bit3(r): the 16-lane groups of a row read (rows taken in the permuted
 // order of perm_row) and the 32-lane halves of a transposed read (rows 8g + q, g in {0,1}) then
-// touch every LDS bank exactly once.
+// touch every LDS bank exactly once.  Rows of 16 bytes (dh = 8) need no swizzle: the 16 rows of a row read and the
+// 2 x 8 rows of a transposed read lie in distinct banks as they are.  A transposed read always covers 16 head-dim
+// columns; with dh = 8 its upper eight come from the NEXT row of the image (16 bytes past the last row for the
+// last one, which the launchers allocate): they only feed output rows d >= 8, which are never stored.
 template <int DH>
 __device__ __forceinline__ int img_swz(int row) {
     return AttnDims<DH>::W == 64 ? ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2)) : 0;
@@ -138,34 +141,36 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* img, int seq0, int col0,
     return u.v;
 }
 
-// stage rows [0,NP) of two [seq][DH] HBM matrices (row strides lda, ldb) into their images; rows >= n and the
-// padding columns of a narrow head are zero.  Every load of the thread is issued before the first LDS write, so a
-// workgroup pays one HBM round trip for its operands rather than one per 16-byte chunk.  blockDim.x = ATTN_THREADS.
-template <int DH, int NP, int THREADS = ATTN_THREADS>
+// stage rows [0,NP) of HPW adjacent heads of two HBM matrices (a head = DH columns; row strides lda, ldb) into
+// their images, head hh at img + hh * NP * W; rows >= n are zero.  Every load of the thread is issued before the
+// first LDS write, so a workgroup pays one HBM round trip for its operands rather than one per 16-byte chunk, and
+// consecutive threads take consecutive 16-byte pieces of a row across the heads.  blockDim.x = THREADS.
+template <int DH, int NP, int THREADS = ATTN_THREADS, int HPW = 1>
 __device__ __forceinline__ void stage_img2(const bf16_t* a, long long lda, bf16_t* img_a, const bf16_t* b, long long ldb,
                                            bf16_t* img_b, int n) {
     using A = AttnDims<DH>;
-    constexpr int TOT = NP * A::CPR;
+    constexpr int PER_ROW = A::CPR * HPW;
+    constexpr int TOT = NP * PER_ROW;
     constexpr int IT = (TOT + THREADS - 1) / THREADS;
     bf16x8 va[IT], vb[IT];
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int c = (int)threadIdx.x + i * THREADS;
-        const int r = c / A::CPR, kc = c % A::CPR;
+        const int r = c / PER_ROW, col = (c % PER_ROW) * 8;
         va[i] = zero8();
         vb[i] = zero8();
-        if (c < TOT && r < n && kc * 8 < DH) {
-            va[i] = *reinterpret_cast<const bf16x8*>(a + (long long)r * lda + kc * 8);
-            vb[i] = *reinterpret_cast<const bf16x8*>(b + (long long)r * ldb + kc * 8);
+        if (c < TOT && r < n) {
+            va[i] = *reinterpret_cast<const bf16x8*>(a + (long long)r * lda + col);
+            vb[i] = *reinterpret_cast<const bf16x8*>(b + (long long)r * ldb + col);
         }
     }
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
         const int c = (int)threadIdx.x + i * THREADS;
-        const int r = c / A::CPR, kc = c % A::CPR;
+        const int r = c / PER_ROW, rem = c % PER_ROW, hh = rem / A::CPR, kc = rem % A::CPR;
         if (c < TOT) {
-            *reinterpret_cast<bf16x8*>(img_a + img_off<DH>(r, kc)) = va[i];
-            *reinterpret_cast<bf16x8*>(img_b + img_off<DH>(r, kc)) = vb[i];
+            *reinterpret_cast<bf16x8*>(img_a + hh * NP * A::W + img_off<DH>(r, kc)) = va[i];
+            *reinterpret_cast<bf16x8*>(img_b + hh * NP * A::W + img_off<DH>(r, kc)) = vb[i];
         }
     }
 }
@@ -311,92 +316,107 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
 // ================================================================ forward (bf16)
 // EXPORT is a template flag of the same kernel.  Chunks of 32 keys that lie wholly beyond N are skipped, only the chunk
 // that straddles N pays for the key mask; exponentials are raw v_exp_f32.
-template <int DH, int NC, bool EXPORT, int THREADS>
+// HPW > 1: a workgroup takes HPW adjacent heads of one image (short sequences of narrow heads: one pair alone is a
+// few kilobytes and five tiles, less than a workgroup's launch and its HBM round trip are worth) and its waves walk
+// the HPW * ceil(N/16) tiles; H must be a multiple of HPW.
+template <int DH, int NC, bool EXPORT, int THREADS, int HPW>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8 ? 4 : (NC <= 16 ? 2 : 1), NC <= 8 ? 4 : (NC <= 16 ? 2 : 1)))) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, bf16_t* __restrict__ probs, int N,
                                                             int H, float scale) {
     using A = AttnDims<DH>;
-    constexpr int NP = NC * 32;
+    constexpr int NP = NC * 32, IMG = NP * A::W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vs = Ks + NP * A::W;
-    const int blk = xcd_block_order();
-    const int b = blk / H, h = blk % H;
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);     // [HPW] K images, then [HPW] V images
+    bf16_t* Vs = Ks + HPW * IMG;
+    const int pair0 = xcd_block_order() * HPW;
+    const int b = pair0 / H, h0 = pair0 % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
-    const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
+    const bf16_t* qb = qkv + (long long)b * N * ld + h0 * DH;
     const bf16_t* kb = qb + I;
     const bf16_t* vb = qb + 2 * I;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
+    const int ntq = (N + 15) >> 4, total = HPW * ntq;
     // export: the wave's 16 x N probability tile is assembled in LDS in its final layout (the 16 rows are one
     // contiguous run of the [B,H,N,N] tensor) and written out with 16-byte stores
-    bf16_t* Pw = Vs + NP * A::W + wave * export_tile_elems(N);
+    bf16_t* Pw = Vs + HPW * IMG + wave * export_tile_elems(N);
     bf16x8 qf[A::KS], qnext[A::KS];                   // the wave's first query tile travels beside the K, V staging
+    auto load_q = [&](int t) {                        // tile t = (head t / ntq, rows 16 (t % ntq) ..); zeros past the end
+        const int hh = HPW == 1 ? 0 : t / ntq, qt = t - hh * ntq;
 #pragma unroll
-    for (int ks = 0; ks < A::KS; ++ks) qnext[ks] = global_frag<DH>(qb, ld, wave * 16 + fr, N, ks, fg);
-    stage_img2<DH, NP, THREADS>(kb, ld, Ks, vb, ld, Vs, N);
+        for (int ks = 0; ks < A::KS; ++ks)
+            qnext[ks] = global_frag<DH>(qb + hh * DH, ld, t < total ? qt * 16 + fr : N, N, ks, fg);
+    };
+    load_q(wave);
+    stage_img2<DH, NP, THREADS, HPW>(kb, ld, Ks, vb, ld, Vs, N);
     __syncthreads();
 
-    for (int qt = wave; qt * 16 < N; qt += nwaves) {
-        const int q = qt * 16 + fr;
+    for (int t = wave; t < total; t += nwaves) {
+        const int hh = HPW == 1 ? 0 : t / ntq, qt = t - hh * ntq;
 #pragma unroll
-        for (int ks = 0; ks < A::KS; ++ks) {          // the next tile's queries load under this tile's arithmetic
-            qf[ks] = qnext[ks];
-            qnext[ks] = global_frag<DH>(qb, ld, q + nwaves * 16, N, ks, fg);
-        }
-        attn_fwd_tile<DH, NC, EXPORT>(Ks, Vs, qf, qt, b, h, N, H, scale, out, lse, probs, Pw, lane);
+        for (int ks = 0; ks < A::KS; ++ks) qf[ks] = qnext[ks];
+        load_q(t + nwaves);                           // the next tile's queries load under this tile's arithmetic
+        attn_fwd_tile<DH, NC, EXPORT>(Ks + hh * IMG, Vs + hh * IMG, qf, qt, b, h0 + hh, N, H, scale, out, lse, probs, Pw, lane);
     }
 }
 
 // ================================================================ backward dK, dV (bf16)
-template <int DH, int NC>
+template <int DH, int NC, int HPW>
 __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                 const bf16_t* __restrict__ dout,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta_in,
                                                                 bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     using A = AttnDims<DH>;
-    constexpr int NP = NC * 32;
+    constexpr int NP = NC * 32, IMG = NP * A::W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* dOs = Qs + NP * A::W;
-    float* lse2 = reinterpret_cast<float*>(dOs + NP * A::W);
-    float* delta = lse2 + NP;
+    bf16_t* Qs_all = reinterpret_cast<bf16_t*>(smem);        // [HPW] Q images, then [HPW] dO images
+    bf16_t* dOs_all = Qs_all + HPW * IMG;
+    float* lse2_all = reinterpret_cast<float*>(dOs_all + HPW * IMG);   // [HPW][NP], then delta [HPW][NP]
+    float* delta_all = lse2_all + HPW * NP;
 
-    const int blk = xcd_block_order();
-    const int b = blk / H, h = blk % H;
+    const int pair0 = xcd_block_order() * HPW;
+    const int b = pair0 / H, h0 = pair0 % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
-    const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
+    const bf16_t* qb = qkv + (long long)b * N * ld + h0 * DH;
     const bf16_t* kb = qb + I;
     const bf16_t* vb = qb + 2 * I;
-    const bf16_t* dob = dout + (long long)b * N * I + h * DH;
+    const bf16_t* dob = dout + (long long)b * N * I + h0 * DH;
     // lse (in log2 units) and delta = rowsum(dO * O) per query, the latter left by the dQ kernel; padded queries
     // get p = 0
-    for (int q = threadIdx.x; q < NP; q += blockDim.x) {
+    for (int i = threadIdx.x; i < HPW * NP; i += blockDim.x) {
+        const int hh = i / NP, q = i - hh * NP;
         float l2 = 1e30f, dl = 0.f;
         if (q < N) {
-            l2 = lse[((long long)b * H + h) * N + q] * LOG2E;
-            dl = delta_in[((long long)b * H + h) * N + q];
+            l2 = lse[((long long)b * H + h0 + hh) * N + q] * LOG2E;
+            dl = delta_in[((long long)b * H + h0 + hh) * N + q];
         }
-        lse2[q] = l2;
-        delta[q] = dl;
+        lse2_all[i] = l2;
+        delta_all[i] = dl;
     }
-    stage_img2<DH, NP>(qb, ld, Qs, dob, I, dOs, N);
+    stage_img2<DH, NP, ATTN_THREADS, HPW>(qb, ld, Qs_all, dob, I, dOs_all, N);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const float sl2 = scale * LOG2E;
     constexpr int nc_act = NC;                        // the launcher picks NC = ceil(N / 32)
-    for (int kt = wave; kt * 16 < N; kt += nwaves) {
+    const int ntk = (N + 15) >> 4;
+    for (int t = wave; t < HPW * ntk; t += nwaves) {
+        const int hh = HPW == 1 ? 0 : t / ntk, kt = t - hh * ntk;
+        const int h = h0 + hh;
+        const bf16_t* Qs = Qs_all + hh * IMG;
+        const bf16_t* dOs = dOs_all + hh * IMG;
+        const float* lse2 = lse2_all + hh * NP;
+        const float* delta = delta_all + hh * NP;
         const int key = kt * 16 + fr;
         bf16x8 kf[A::KS], vf[A::KS];
 #pragma unroll
         for (int ks = 0; ks < A::KS; ++ks) {
-            kf[ks] = global_frag<DH>(kb, ld, key, N, ks, fg);
-            vf[ks] = global_frag<DH>(vb, ld, key, N, ks, fg);
+            kf[ks] = global_frag<DH>(kb + hh * DH, ld, key, N, ks, fg);
+            vf[ks] = global_frag<DH>(vb + hh * DH, ld, key, N, ks, fg);
         }
         f32x4 dkt[A::DT], dvt[A::DT];
 #pragma unroll
@@ -454,7 +474,7 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
 }
 
 // ================================================================ backward dQ (bf16)
-template <int DH, int NC>
+template <int DH, int NC, int HPW>
 __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8 ? 4 : 2, NC <= 8 ? 4 : 2))) void attn_bwd_dq_bf16_kernel(const bf16_t* __restrict__ qkv,
                                                                const bf16_t* __restrict__ out,
                                                                const bf16_t* __restrict__ dout,
@@ -462,41 +482,48 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(NC
                                                                float* __restrict__ delta_out,
                                                                bf16_t* __restrict__ dqkv, int N, int H, float scale) {
     using A = AttnDims<DH>;
-    constexpr int NP = NC * 32;
+    constexpr int NP = NC * 32, IMG = NP * A::W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vs = Ks + NP * A::W;
+    bf16_t* Ks_all = reinterpret_cast<bf16_t*>(smem);        // [HPW] K images, then [HPW] V images
+    bf16_t* Vs_all = Ks_all + HPW * IMG;
 
-    const int blk = xcd_block_order();
-    const int b = blk / H, h = blk % H;
+    const int pair0 = xcd_block_order() * HPW;
+    const int b = pair0 / H, h0 = pair0 % H;
     const int I = H * DH;
     const long long ld = 3ll * I;
-    const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
+    const bf16_t* qb = qkv + (long long)b * N * ld + h0 * DH;
     const bf16_t* kb = qb + I;
     const bf16_t* vb = qb + 2 * I;
-    const bf16_t* ob = out + (long long)b * N * I + h * DH;
-    const bf16_t* dob = dout + (long long)b * N * I + h * DH;
+    const bf16_t* ob = out + (long long)b * N * I + h0 * DH;
+    const bf16_t* dob = dout + (long long)b * N * I + h0 * DH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
+    const int ntq = (N + 15) >> 4, total = HPW * ntq;
     // the wave's first query tile (q, dO, O, lse) travels beside the K, V staging; later tiles load one tile ahead
     bf16x8 qf[A::KS], dof[A::KS], qn[A::KS], don[A::KS], on[A::KS];
     float lsen;
-    {
-        const int q = wave * 16 + fr;
+    auto load_tile = [&](int t) {                     // tile t = (head t / ntq, rows 16 (t % ntq) ..); zeros past the end
+        const int hh = HPW == 1 ? 0 : t / ntq, qt = t - hh * ntq;
+        const int q = t < total ? qt * 16 + fr : N;
 #pragma unroll
         for (int ks = 0; ks < A::KS; ++ks) {
-            qn[ks] = global_frag<DH>(qb, ld, q, N, ks, fg);
-            don[ks] = global_frag<DH>(dob, I, q, N, ks, fg);
-            on[ks] = global_frag<DH>(ob, I, q, N, ks, fg);
+            qn[ks] = global_frag<DH>(qb + hh * DH, ld, q, N, ks, fg);
+            don[ks] = global_frag<DH>(dob + hh * DH, I, q, N, ks, fg);
+            on[ks] = global_frag<DH>(ob + hh * DH, I, q, N, ks, fg);
         }
-        lsen = q < N ? lse[((long long)b * H + h) * N + q] : 1e30f;
-    }
-    stage_img2<DH, NP>(kb, ld, Ks, vb, ld, Vs, N);
+        lsen = q < N ? lse[((long long)b * H + h0 + hh) * N + q] : 1e30f;
+    };
+    load_tile(wave);
+    stage_img2<DH, NP, ATTN_THREADS, HPW>(kb, ld, Ks_all, vb, ld, Vs_all, N);
     __syncthreads();
 
     const float sl2 = scale * LOG2E;
     constexpr int nc_act = NC;                        // the launcher picks NC = ceil(N / 32)
-    for (int qt = wave; qt * 16 < N; qt += nwaves) {
+    for (int t = wave; t < total; t += nwaves) {
+        const int hh = HPW == 1 ? 0 : t / ntq, qt = t - hh * ntq;
+        const int h = h0 + hh;
+        const bf16_t* Ks = Ks_all + hh * IMG;
+        const bf16_t* Vs = Vs_all + hh * IMG;
         const int q = qt * 16 + fr;
         float dl = 0.f;
 #pragma unroll
@@ -511,16 +538,7 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(NC
         if (fg == 0 && q < N) delta_out[((long long)b * H + h) * N + q] = dl;   // the dK, dV kernel reads it
         // p * 1/sqrt(dh) comes straight out of the exponential: log2 of the factor joins the exponent
         const float l2 = q < N ? lsen * LOG2E - __log2f(scale) : 1e30f;
-        {
-            const int q2 = q + nwaves * 16;
-#pragma unroll
-            for (int ks = 0; ks < A::KS; ++ks) {
-                qn[ks] = global_frag<DH>(qb, ld, q2, N, ks, fg);
-                don[ks] = global_frag<DH>(dob, I, q2, N, ks, fg);
-                on[ks] = global_frag<DH>(ob, I, q2, N, ks, fg);
-            }
-            lsen = q2 < N ? lse[((long long)b * H + h) * N + q2] : 1e30f;
-        }
+        load_tile(t + nwaves);
         f32x4 dqt[A::DT];
 #pragma unroll
         for (int dt = 0; dt < A::DT; ++dt) dqt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -776,13 +794,13 @@ inline int pick_nc(int N) {
     return 0;
 }
 
-template <int DH, int NC>
+template <int DH, int NC, int HPW = 1>
 size_t dkv_smem() {
-    return (size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t) + 2 * NC * 32 * sizeof(float);
+    return (size_t)HPW * ((size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t) + 2 * NC * 32 * sizeof(float)) + 16;
 }
-template <int DH, int NC>
+template <int DH, int NC, int HPW = 1>
 size_t dq_smem() {
-    return (size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t);
+    return (size_t)HPW * (2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t) + 16;
 }
 
 // Raise a kernel's dynamic-LDS limit once per device (the attribute is per device; one process
@@ -799,24 +817,33 @@ inline int ensure_lds(const void* fn, size_t bytes, unsigned long long* done_mas
     return VITMI_OK;
 }
 
-template <int DH, int NC>
+template <int DH, int NC, int HPW = 1>
 size_t fwd_smem() {
-    return (size_t)(2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t);
+    return (size_t)HPW * (2 * NC * 32 * AttnDims<DH>::W) * sizeof(bf16_t) + 16;
 }
 
-template <int DH, int NC, bool EXPORT, int THREADS>
+// heads per workgroup: 6 for short sequences (<= 96 tokens) of narrow heads (<= 16 wide) when the head count allows
+// it and the grid still covers the chip; otherwise one (image, head) pair per workgroup
+constexpr int HPW_SMALL = 6;
+inline bool use_head_groups(int B, int N, int H, int DH) {
+    return DH <= 16 && N <= 96 && H % HPW_SMALL == 0 && (long long)B * H / HPW_SMALL >= 256;
+}
+
+int g_attn_head_groups = 1;      // debug switch: 0 = one (image, head) pair per workgroup for every shape
+
+template <int DH, int NC, bool EXPORT, int THREADS, int HPW = 1>
 int launch_fwd_t(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
     const float scale = 1.0f / sqrtf((float)DH);
     static unsigned long long done = 0;
     // the export variant adds one tile buffer per wave
-    const size_t sm = fwd_smem<DH, NC>() + (EXPORT ? (size_t)(THREADS / 64) * export_tile_elems(N) * sizeof(bf16_t) : 0);
+    const size_t sm = fwd_smem<DH, NC, HPW>() + (EXPORT ? (size_t)(THREADS / 64) * export_tile_elems(N) * sizeof(bf16_t) : 0);
     const size_t sm_max = THREADS > ATTN_THREADS ? LDS_BYTES
-                                                 : fwd_smem<DH, NC>() + (EXPORT ? (size_t)(THREADS / 64) * export_tile_elems(NC * 32) * sizeof(bf16_t) : 0);
-    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH, NC, EXPORT, THREADS>), sm_max, &done,
+                                                 : fwd_smem<DH, NC, HPW>() + (EXPORT ? (size_t)(THREADS / 64) * export_tile_elems(NC * 32) * sizeof(bf16_t) : 0);
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_bf16_kernel<DH, NC, EXPORT, THREADS, HPW>), sm_max, &done,
                         "vitmi_attn_fwd: LDS attribute");
     if (rc != VITMI_OK) return rc;
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC, EXPORT, THREADS>), dim3(B * H), dim3(THREADS), sm, s, (const bf16_t*)qkv,
-                       (bf16_t*)out, lse, (bf16_t*)probs, N, H, scale);
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC, EXPORT, THREADS, HPW>), dim3(B * H / HPW), dim3(THREADS), sm, s,
+                       (const bf16_t*)qkv, (bf16_t*)out, lse, (bf16_t*)probs, N, H, scale);
     VITMI_LAUNCH_CHECK("vitmi_attn_fwd(bf16)");
     return VITMI_OK;
 }
@@ -825,6 +852,10 @@ int launch_fwd_t(const void* qkv, void* out, float* lse, void* probs, int B, int
 // lengths: it then runs 16 waves per workgroup (the occupancy of two 8-wave workgroups) when those tiles fit.
 template <int DH, int NC, bool EXPORT>
 int launch_fwd_x(const void* qkv, void* out, float* lse, void* probs, int B, int N, int H, hipStream_t s) {
+    if constexpr (DH <= 16 && NC <= 3) {
+        if (g_attn_head_groups && use_head_groups(B, N, H, DH))
+            return launch_fwd_t<DH, NC, EXPORT, ATTN_THREADS, HPW_SMALL>(qkv, out, lse, probs, B, N, H, s);
+    }
     if constexpr (EXPORT) {
         const size_t one = fwd_smem<DH, NC>() + (size_t)(ATTN_THREADS / 64) * export_tile_elems(N) * sizeof(bf16_t);
         const size_t wide = fwd_smem<DH, NC>() + (size_t)(2 * ATTN_THREADS / 64) * export_tile_elems(N) * sizeof(bf16_t);
@@ -846,24 +877,34 @@ int launch_fwd(const void* qkv, void* out, float* lse, void* probs, int B, int N
     return launch_fwd_x<DH, NC, false>(qkv, out, lse, probs, B, N, H, s);
 }
 
+template <int DH, int NC, int HPW>
+int launch_bwd_t(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
+                 int N, int H, hipStream_t s) {
+    const float scale = 1.0f / sqrtf((float)DH);
+    static unsigned long long done1 = 0, done2 = 0;
+    const size_t s1 = dkv_smem<DH, NC, HPW>(), s2 = dq_smem<DH, NC, HPW>();
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_dkv_bf16_kernel<DH, NC, HPW>), s1, &done1, "vitmi_attn_bwd: LDS attribute (dkv)");
+    if (rc != VITMI_OK) return rc;
+    rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_dq_bf16_kernel<DH, NC, HPW>), s2, &done2, "vitmi_attn_bwd: LDS attribute (dq)");
+    if (rc != VITMI_OK) return rc;
+    // dQ first: it leaves delta = rowsum(dO * O) per query in the workspace for the dK, dV kernel
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DH, NC, HPW>), dim3(B * H / HPW), dim3(ATTN_THREADS), s2, s,
+                       (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dq, bf16)");
+    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DH, NC, HPW>), dim3(B * H / HPW), dim3(ATTN_THREADS), s1, s,
+                       (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dkv, bf16)");
+    return VITMI_OK;
+}
+
 template <int DH, int NC>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, float* delta, void* dqkv, int B,
                int N, int H, hipStream_t s) {
-    const float scale = 1.0f / sqrtf((float)DH);
-    static unsigned long long done1 = 0, done2 = 0;
-    const size_t s1 = dkv_smem<DH, NC>(), s2 = dq_smem<DH, NC>();
-    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_dkv_bf16_kernel<DH, NC>), s1, &done1, "vitmi_attn_bwd: LDS attribute (dkv)");
-    if (rc != VITMI_OK) return rc;
-    rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_dq_bf16_kernel<DH, NC>), s2, &done2, "vitmi_attn_bwd: LDS attribute (dq)");
-    if (rc != VITMI_OK) return rc;
-    // dQ first: it leaves delta = rowsum(dO * O) per query in the workspace for the dK, dV kernel
-    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DH, NC>), dim3(B * H), dim3(ATTN_THREADS), s2, s, (const bf16_t*)qkv,
-                       (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
-    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dq, bf16)");
-    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DH, NC>), dim3(B * H), dim3(ATTN_THREADS), s1, s, (const bf16_t*)qkv,
-                       (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
-    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dkv, bf16)");
-    return VITMI_OK;
+    if constexpr (DH <= 16 && NC <= 3) {
+        if (g_attn_head_groups && use_head_groups(B, N, H, DH))
+            return launch_bwd_t<DH, NC, HPW_SMALL>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
+    }
+    return launch_bwd_t<DH, NC, 1>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
 }
 
 #define DISPATCH_NC(FN, DH, ...)                      \
@@ -910,6 +951,11 @@ int check_common(const char* who, int dt, int B, int N, int H, int DH) {
 }
 
 }  // namespace
+
+extern "C" int vitmi_debug_set_attn_head_groups(int on) {
+    g_attn_head_groups = on;
+    return VITMI_OK;
+}
 
 extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, int B, int N, int H, int DH,
                               void* stream) {
