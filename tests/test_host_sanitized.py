@@ -1,0 +1,52 @@
+"""The host side of the C-ABI library under UndefinedBehaviorSanitizer (trap mode: a finding kills the process with
+SIGILL).  Runs in a child process so that a trap is a failed test, not a dead test runner.  Needs
+`python visiontransformer_amd/build.py --host-sanitize`; skipped when that library has not been built.  No GPU: only
+entry points and arguments that return before the first device call (size queries, argument checks)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "visiontransformer_amd", "libvitmi_hip_hostsan.so")
+
+CHILD = r"""
+import ctypes, os, sys
+sys.path.insert(0, sys.argv[2])
+os.environ["VITMI_LIB"] = sys.argv[1]
+from visiontransformer_amd import _lib
+lib = _lib.lib
+big = 2 ** 31 - 1
+# workspace arithmetic at the benchmark's sizes and at the largest ints the signatures take: no signed overflow
+for dt in (_lib.F32, _lib.BF16):
+    assert lib.vitmi_attn_bwd_workspace_bytes(dt, 256, 197, 12, 64) > 0
+    assert lib.vitmi_attn_bwd_dprobs_workspace_bytes(dt, 256, 197, 12, 64) > 0
+    assert lib.vitmi_gemm_wgrad_workspace_bytes(dt, 3072, 768, 50432) >= 0
+    assert lib.vitmi_ff_block_bwd_workspace_bytes(dt, 50432, 768, 3072) > 0
+    assert lib.vitmi_attn_block_bwd_workspace_bytes(dt, 256, 197, 768, 12, 64) > 0
+    assert lib.vitmi_wgrad_sqnorm_workspace_bytes(dt, 3072, 768, 50432, 197) >= 0
+    lib.vitmi_attn_bwd_workspace_bytes(dt, big, 608, 64, 64)
+    lib.vitmi_attn_bwd_dprobs_workspace_bytes(dt, 4096, 256, 64, 64)
+    lib.vitmi_patch_embed_bwd_w_workspace_bytes(dt, 4096, 3, 224, 224, 16, 768)
+assert lib.vitmi_gemm_colsum_workspace_bytes(50432, 3072) > 0
+assert lib.vitmi_colsum_workspace_bytes(2 ** 40, 4096) > 0
+assert lib.vitmi_layernorm_bwd_workspace_bytes(2 ** 40, 1024) > 0
+assert lib.vitmi_rollout_workspace_bytes(12, 256, 197) > 0
+assert lib.vitmi_tokens_assemble_bwd_workspace_bytes(197, 768) > 0
+# argument checks: a clean error code and a message, never a crash
+assert lib.vitmi_attn_fwd(None, None, None, None, _lib.BF16, 1, 1, 1, 64, None) != 0 and lib.vitmi_last_error()
+assert lib.vitmi_attn_bwd(None, None, None, None, None, None, None, _lib.BF16, 1, 1, 1, 64, None) != 0
+assert lib.vitmi_set_reserved_cus(7) != 0 and b"multiple of 8" in lib.vitmi_last_error()
+assert lib.vitmi_set_reserved_cus(0) == 0
+for knob in ("vitmi_debug_set_nt_group", "vitmi_debug_set_nt_tail_split", "vitmi_debug_set_gelu_pair",
+             "vitmi_debug_set_attn_head_groups"):
+    getattr(lib, knob)(1)
+print("host-sanitized checks ok")
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(LIB), reason="libvitmi_hip_hostsan.so not built (build.py --host-sanitize)")
+def test_size_queries_and_argument_checks_under_ubsan():
+    r = subprocess.run([sys.executable, "-c", CHILD, LIB, ROOT], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "host-sanitized checks ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])

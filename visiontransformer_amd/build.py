@@ -3,6 +3,11 @@
 The library is plain HIP + C ABI (no torch headers), so a build is a handful of hipcc
 invocations; objects are cached under csrc/build/ and rebuilt when their source or a header
 is newer.
+
+`python visiontransformer_amd/build.py --host-sanitize` builds libvitmi_hip_hostsan.so beside it: the same sources with
+the HOST side of every translation unit (argument checks, workspace arithmetic, launch geometry) under
+-fsanitize=undefined in trap mode (no sanitizer runtime to load, a finding stops the process with SIGILL); device code
+is unchanged (GPU sanitizers are not available on the target pool).  Load it with VITMI_LIB=<path>.
 """
 import concurrent.futures
 import os
@@ -34,12 +39,17 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+HOSTSAN_FLAGS = ["-Xarch_host", "-fsanitize=undefined", "-Xarch_host", "-fsanitize-trap=undefined", "-Xarch_host",
+                 "-fno-sanitize=vptr,function"]
+HOSTSAN_LIB = os.path.join(HERE, "libvitmi_hip_hostsan.so")
+
+
+def _compile(src, obj_dir=None, extra=()):
+    obj = os.path.join(obj_dir or OBJ, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     hdrs = HEADERS + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     if _stale(obj, [path] + hdrs):
-        cmd = [_hipcc()] + FLAGS + ["-c", path, "-o", obj]
+        cmd = [_hipcc()] + FLAGS + list(extra) + ["-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
@@ -68,5 +78,24 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_host_sanitized(verbose=True):
+    obj_dir = os.path.join(CSRC, "build_hostsan")
+    os.makedirs(obj_dir, exist_ok=True)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        results = list(ex.map(lambda src: _compile(src, obj_dir, HOSTSAN_FLAGS), SOURCES))
+    objs = [o for o, _ in results]
+    if any(r for _, r in results) or _stale(HOSTSAN_LIB, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", HOSTSAN_LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"built {HOSTSAN_LIB}")
+    return HOSTSAN_LIB
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--host-sanitize" in sys.argv:
+        build_host_sanitized()
+    else:
+        build(force="--force" in sys.argv)
