@@ -118,6 +118,30 @@ def test_graphed_forward_backward_matches_eager():
         o1.step()
         o2.step()
     assert all(torch.equal(a, b) for a, b in zip(m1.parameters(), m2.parameters()))
+    # an optimizer that changes the parameters through torch ops (their version moves, the cached compute copies
+    # go stale) and a cleared cache in between: the graph must still compute with the current weights
+    from visiontransformer_amd import ops
+
+    def make_sgd():
+        torch.manual_seed(4)
+        m = ViT_mask.VIT(**kw).to(dev).train()
+        m.train_method = "mask"
+        return m, torch.optim.SGD(m.parameters(), lr=0.05)
+
+    m4, o4 = make_sgd()
+    m5, o5 = make_sgd()
+    g5 = GraphedForwardBackward(m5, ce, xs[0], ys[0], masks[0])
+    for i, (x, y, um) in enumerate(zip(xs, ys, masks)):
+        o4.zero_grad()
+        l4 = ce(m4(x, unk_mask=um), y)
+        l4.backward()
+        l5 = g5(x, y, um)
+        assert torch.equal(l4.detach(), l5.detach()), i
+        o4.step()
+        o5.step()
+        if i == 1:
+            ops.clear_cast_cache()
+    assert all(torch.equal(a, b) for a, b in zip(m4.parameters(), m5.parameters()))
     m3 = ViT_mask.VIT(dropout=0.1, **kw).to(dev).train()
     with pytest.raises(ValueError, match="dropout"):
         GraphedForwardBackward(m3, ce, xs[0], ys[0], masks[0])

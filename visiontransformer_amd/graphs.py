@@ -10,8 +10,14 @@ Shapes are fixed at capture.  Inputs are copied into static tensors before each 
 model takes one, is a static device tensor refreshed the same way.  Code that decides anything on the host from
 device values cannot be captured; the dropouts inside the blocks draw their seeds on the host, so a model with
 block dropout > 0 would replay the same masks every step and is rejected here.
+
+The graph reads the weights from the compute copies (bf16 and transposed bf16) that existed at capture.  Before every
+replay those very buffers are brought up to date in place when a parameter has changed since (any optimizer that
+modifies parameters through torch ops, load_state_dict, a cleared cache); the fused Adam kernel refreshes them itself.
 """
 import torch
+
+from . import ops
 
 
 class GraphedForwardBackward:
@@ -43,6 +49,7 @@ class GraphedForwardBackward:
             self.loss = self._run()
             self.loss.backward()
         self.grads = [p.grad for p in self.params]       # static: every replay rewrites these tensors
+        self._pinned = ops.pinned_compute_copies(list(model.parameters()))
 
     def _run(self):
         out = self.model(self.x, unk_mask=self.unk) if self.unk is not None else self.model(self.x)
@@ -57,5 +64,6 @@ class GraphedForwardBackward:
             self.unk.copy_(unk_mask, non_blocking=True)
         for p, g in zip(self.params, self.grads):
             p.grad = g
+        ops.refresh_pinned_copies(self._pinned)
         self.graph.replay()
         return self.loss

@@ -151,6 +151,37 @@ def compute_copy_t(param, dtype):
     return out
 
 
+def pinned_compute_copies(params):
+    """(key, parameter, copy) of every cached compute copy of the given parameters: the buffers a captured graph
+    reads the weights from."""
+    wanted = {id(p): p for p in params}
+    out = []
+    for key, (_, _, copy, ref) in list(_cast_cache.items()):
+        p = wanted.get(key[0])
+        if p is not None and ref() is p:
+            out.append((key, p, copy))
+    return out
+
+
+def refresh_pinned_copies(pinned):
+    """Bring pinned compute copies up to date IN PLACE.  A captured graph keeps reading the buffers it was captured
+    with; when a parameter was modified since (an optimizer that goes through autograd-visible in-place ops, a
+    load_state_dict) or the cache was cleared, the cache would hand eager code a NEW buffer and the graph would go
+    on computing with the old weights.  This rewrites the old buffers and re-registers them as the current copies."""
+    for key, p, copy in pinned:
+        ent = _cast_cache.get(key)
+        if (ent is not None and ent[2] is copy and ent[3]() is p and ent[0] == p._version
+                and ent[1] == p.data_ptr()):
+            continue
+        src = p.detach().contiguous()
+        if len(key) == 3:       # transposed copy
+            n, k = src.shape
+            check(lib.vitmi_transpose_cast(_p(src), _dt(src), _p(copy), n, k, _stream()), "vitmi_transpose_cast")
+        else:
+            check(lib.vitmi_cast(_p(src), _dt(src), _p(copy), _dt(copy.dtype), src.numel(), _stream()), "vitmi_cast")
+        _cache_store(key, p, copy)
+
+
 def clear_cast_cache():
     """Drop every cached compute copy (call after parameters were changed behind autograd's back,
     e.g. by the fused optimizer kernel)."""
