@@ -146,3 +146,30 @@ def test_vit_b16_block_at_batch_128_against_oracle():
     assert abs(loss.item() - loss_ref.item()) < 2e-2 * max(1.0, abs(loss_ref.item()))
     worst = max((rel_err(p.grad, grads_ref[k]), k) for k, p in m.named_parameters())
     assert worst[0] < 2e-2, worst
+
+
+@pytest.mark.parametrize("dtype,tol,B", [(torch.float32, 1e-4, 8), (BF, 2e-2, 32)])
+def test_vit_b16_full_depth_against_oracle(dtype, tol, B):
+    """The benchmark's model at its full depth (12 blocks of D 768, H 12, dh 64, mlp 3072, 197 tokens): what twelve
+    layers of rounding add up to, against the CPU oracle.  Logits, loss and every gradient.  bf16 at batch 32: worst
+    gradient 1.4e-2 by the maximum measure, 1.1e-2 rms; at batch 8 single elements of single tensors (the classifier
+    weight, one LayerNorm weight) reach 2.2-2.4e-2 with the rms at 1.2e-2 (tools/depth_diag.py): a gradient element
+    there is a sum over eight images only."""
+    from visiontransformer_amd import ViT
+    kw = dict(image_size=224, patch_size=16, embed_dim=768, num_classes=100, depth=12, heads=12, mlp_dim=3072,
+              dim_head=64)
+    params = vit_oracle.init_params(masked=False, seed=9, **kw)
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(B, 3, 224, 224, generator=g)
+    y = torch.randint(0, 100, (B,), generator=g)
+    logits_ref, loss_ref, grads_ref = vit_oracle.loss_and_grads(params, x, y, 12)
+    m = ViT.VIT(**kw)
+    m.load_state_dict(params)
+    m = m.to(DEV).set_compute_dtype(dtype).train()
+    logits = m(x.to(DEV))
+    loss = torch.nn.functional.cross_entropy(logits, y.to(DEV))
+    loss.backward()
+    assert rel_err(logits, logits_ref) < tol
+    assert abs(loss.item() - loss_ref.item()) < tol * max(1.0, abs(loss_ref.item()))
+    errs = sorted(((rel_err(p.grad, grads_ref[k]), k) for k, p in m.named_parameters()), reverse=True)
+    assert errs[0][0] < tol, errs[:5]
