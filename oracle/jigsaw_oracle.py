@@ -1,8 +1,8 @@
 """CPU oracle for the image half of the jigsaw augmentation (TEST INFRASTRUCTURE, not product code).
 
 Restates JigsawPuzzleMaskedRegion.__call__ of the reference in numpy:
-  masking_generator.py:144-199 (branches "mjp", "pbf", "orain", "zero", "repeat"); the "mjp" branch
-  is the same text as utils/masking_generator.py:156-171.
+  masking_generator.py:144-221 (every branch); the "mjp" branch is the same text as
+  utils/masking_generator.py:156-171.
 Every branch is: Unfold(p, stride p) -> overwrite the masked columns -> Fold back, followed by the
 class-token padding of the mask.  Unfold/Fold for kernel = stride are restated as the index map
   patches[n, (c*p + ky)*p + kx, gy*gw + gx] = x[n, c, gy*p + ky, gx*p + kx]        (torch.nn.Unfold).
@@ -14,7 +14,11 @@ only, one np.random.choice(arange(P), N, replace=False) afterwards (masking_gene
 Pinning: the "mjp" branch is pinned by tests/golden/jigsaw_mjp.npz, captured from the reference's
 importable utils/masking_generator.JigsawPuzzleMaskedRegion.  The module that holds the other
 branches (masking_generator.py at the reference's root) imports torchvision, which this image does
-not have: "pbf", "zero" and "repeat" are PARITY UNPINNED -- restated from the text only.
+not have; tools/gen_golden.py compiles its two class definitions alone (MaskingGenerator,
+JigsawPuzzleMaskedRegion) out of the file and hands the constructor a synthetic patch bank in place of
+the image-folder reader, and tests/golden/jigsaw_modes.npz holds what every other branch ("pbf",
+"orain", "zero", "repeat", "exchange", "Scale", "noise", an unknown name) returned: all PINNED, bit
+for bit except "repeat" (the fp32 mean is summed in another order: 2e-6).
 """
 import numpy as np
 

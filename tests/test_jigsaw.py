@@ -1,8 +1,8 @@
-"""JigsawPuzzleMaskedRegion: the numpy oracle against the vectors captured from the reference's
-utils/masking_generator ("mjp"), and the HIP gather against both.  Patch movement is pure copying, so
-"mjp", "pbf" and "zero" are compared bit for bit; "repeat" averages in fp32 and is held to 1e-6
-(fp32) / one bf16 ulp.  "pbf", "zero" and "repeat" have no reference vectors (their module needs
-torchvision, absent here): parity unpinned, checked against the text restatement only."""
+"""JigsawPuzzleMaskedRegion: the numpy oracle against vectors captured from the reference -- "mjp" from the
+importable utils/masking_generator (jigsaw_mjp.npz), every other branch from the class definitions of the top-level
+masking_generator.py compiled out of the file (its imports need torchvision), with the public patch bank handed in as
+data (jigsaw_modes.npz; tools/gen_golden.py) -- and the HIP gather against both.  Patch movement is pure copying, so
+those branches are compared bit for bit; "repeat" averages in fp32 (summation order differs: 2e-6 / one bf16 ulp)."""
 import os
 import random
 
@@ -34,6 +34,34 @@ def test_oracle_matches_reference_vectors():
         assert mk.dtype == np.int32 and mk.shape == (1, (m["img"] // m["p"]) ** 2 + 1)
         n += 1
     assert n == 7
+
+
+def golden_modes():
+    z = np.load(os.path.join(GOLDEN, "jigsaw_modes.npz"), allow_pickle=False)
+    for k in z["keys"]:
+        k = str(k)
+        g, mode, seed = k.split("/")
+        img, p, nmask, nmin, B, C = (int(v) for v in z[g + "/meta"])
+        masks = z[k + "/masks"]
+        yield k, dict(img=img, p=p, nmask=nmask, nmin=nmin, B=B, C=C, seed=int(seed), mode=mode), z[k + "/x"], \
+            z[k + "/out"], (masks if masks.size else None), z[g + "/bank"]
+
+
+def test_oracle_matches_reference_vectors_of_every_branch():
+    seen = set()
+    for k, m, x, out, masks, bank in golden_modes():
+        random.seed(m["seed"]), np.random.seed(m["seed"]), torch.manual_seed(m["seed"])
+        o, mk = jigsaw_oracle.jigsaw(x.copy(), m["p"], m["nmask"], m["nmin"], m["mode"], bank)
+        if m["mode"] == "repeat":
+            np.testing.assert_allclose(o, out, rtol=0, atol=2e-6 * max(1.0, np.abs(out).max()), err_msg=k)
+        else:
+            np.testing.assert_array_equal(o, out, err_msg=k)
+        if masks is None:
+            assert mk is None, k
+        else:
+            np.testing.assert_array_equal(mk, masks, err_msg=k)
+        seen.add(m["mode"])
+    assert seen == {"pbf", "orain", "zero", "repeat", "exchange", "Scale", "noise", "pps"}
 
 
 def test_oracle_unfold_fold_round_trip_and_branch_properties():
@@ -110,6 +138,27 @@ def test_hip_mjp_matches_reference_vectors(dtype):
         assert torch.equal(xt, keep)                                    # the input batch is left as it was
         want = torch.from_numpy(out).to(DEV).to(dtype)                  # a copy commutes with the rounding
         assert got.dtype == dtype and torch.equal(got, want), k
+
+
+@pytest.mark.gpu
+def test_hip_branches_match_reference_vectors():
+    from visiontransformer_amd.masking_generator import JigsawPuzzleMaskedRegion
+    n = 0
+    for k, m, x, out, masks, bank in golden_modes():
+        j = JigsawPuzzleMaskedRegion(m["img"], m["p"], m["nmask"], m["nmin"], mask_type=m["mode"], channels=m["C"],
+                                     device=DEV, pub_data=torch.from_numpy(bank))
+        random.seed(m["seed"]), np.random.seed(m["seed"]), torch.manual_seed(m["seed"])
+        got, mk = j(torch.from_numpy(x).to(DEV))
+        if masks is None:
+            assert mk is None, k
+        else:
+            np.testing.assert_array_equal(mk, masks, err_msg=k)
+        if m["mode"] == "repeat":
+            assert (got.cpu() - torch.from_numpy(out)).abs().max().item() <= 2e-6 * max(1.0, np.abs(out).max()), k
+        else:
+            assert torch.equal(got.cpu(), torch.from_numpy(out)), k
+        n += 1
+    assert n == 48
 
 
 @pytest.mark.gpu

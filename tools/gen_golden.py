@@ -131,6 +131,8 @@ def main():
 
     if not only or "jigsaw" in only:
         gen_jigsaw()
+    if not only or "jigsaw_modes" in only:
+        gen_jigsaw_modes()
     if not only or "rollout" in only:
         gen_rollout()
     if not only or "grad_rollout" in only:
@@ -193,6 +195,57 @@ def gen_jigsaw():
     path = os.path.join(OUT, "jigsaw_mjp.npz")
     np.savez_compressed(path, **arr)
     print("jigsaw", len(arr["keys"]), "bytes", os.path.getsize(path))
+
+
+def gen_jigsaw_modes():
+    """Every branch of JigsawPuzzleMaskedRegion.__call__ of the top-level masking_generator.py (:144-221) besides
+    "mjp" -> tests/golden/jigsaw_modes.npz.  That module imports torchvision and the image-folder reader
+    dataloader.public_data at its top, neither usable here, so only the two class definitions (MaskingGenerator,
+    JigsawPuzzleMaskedRegion) are compiled out of the file with ast; the name `public_data` the constructor calls is
+    bound to a function that returns the synthetic patch bank stored in the fixture (the reader is I/O, the bank is an
+    input).  Images, seeds of the three generators the class draws from (random, numpy, torch), outputs and masks."""
+    import ast
+    import copy
+    import math
+    path = os.path.join(REF, "masking_generator.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    names = ["MaskingGenerator", "JigsawPuzzleMaskedRegion"]
+    body = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+    assert sorted(n.name for n in body) == sorted(names)
+    bank_box = {}
+    ns = {"torch": torch, "np": np, "random": random, "math": math, "copy": copy,
+          "public_data": lambda **kw: bank_box["bank"].clone()}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    Jig = ns["JigsawPuzzleMaskedRegion"]
+    arr, keys, failed = {}, [], {}
+    geoms = [(32, 4, 32, 4, 3, 3), (24, 2, 60, 4, 2, 3), (28, 14, 2, 1, 3, 2)]
+    for gi, (img, p, nmask, nmin, B, C) in enumerate(geoms):
+        L = (img // p) ** 2
+        torch.manual_seed(300 + gi)
+        bank_box["bank"] = torch.randn(7, C * p * p, L)
+        arr[f"g{gi}/bank"] = bank_box["bank"].numpy()
+        arr[f"g{gi}/meta"] = np.array([img, p, nmask, nmin, B, C], dtype=np.int64)
+        for mode in ("pbf", "orain", "zero", "repeat", "exchange", "Scale", "noise", "pps"):
+            for seed in (5, 1234):
+                torch.manual_seed(100 + seed)
+                x = torch.randn(B, C, img, img) * (40.0 if mode == "noise" else 1.0)    # so that the clip at 0 acts
+                jig = Jig(img_size=img, patch_size=p, num_masking_patches=nmask, min_num_patches=nmin, mask_type=mode,
+                          channels=C, device=torch.device("cpu"))
+                random.seed(seed), np.random.seed(seed), torch.manual_seed(seed)
+                try:
+                    out, masks = jig(x.clone())
+                except Exception as e:      # a branch that cannot run in the reference has no vector
+                    failed[mode] = f"{type(e).__name__}: {e}"
+                    continue
+                k = f"g{gi}/{mode}/{seed}"
+                keys.append(k)
+                arr[k + "/x"] = x.numpy()
+                arr[k + "/out"] = out.detach().numpy()
+                arr[k + "/masks"] = masks if masks is not None else np.zeros((0,), dtype=np.int32)
+    arr["keys"] = np.array(keys)
+    out_path = os.path.join(OUT, "jigsaw_modes.npz")
+    np.savez_compressed(out_path, **arr)
+    print("jigsaw modes", len(keys), "bytes", os.path.getsize(out_path), "branches that raise in the reference:", failed)
 
 
 def _reference_functions(path, names):
