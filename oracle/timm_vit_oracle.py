@@ -6,9 +6,13 @@ tim/models/vision_transformer.py: Attention.forward (:80-102, non-fused branch),
 (:156-159), _pos_embed (:556-564), forward_features (:615-624), forward_head / forward (:626-637),
 with LayerNorm eps 1e-6 (:454) and erf GELU (:455).  Backward is torch autograd over this forward.
 
-PARITY UNPINNED: that module cannot be imported in the build container (it needs torchvision and
-the external timm package, neither installed) and the reference has no tests or fixtures for it,
-so nothing here was checked against the reference's own execution -- only against its text.
+PINNED: the module cannot be imported in the build container (tim/__init__ pulls torchvision, and the
+file imports the external timm package), so tools/gen_golden.py compiles the class definitions
+VisionTransformer, Block, Attention, LayerScale out of the file, and PatchEmbed, Mlp, DropPath and the
+few helpers their constructors call out of the reference's vendored tim/layers, and runs them:
+tests/golden/timm_*.npz hold state_dict, inputs, logits, loss, every gradient, per-layer probabilities
+and token features for token / avg pooling, masked and unmasked, heads of 16 and 64.
+tests/test_timm_golden.py holds this restatement to 2e-5 (forward) / 5e-5 (gradients) against them.
 
 Only tests/ may import this module.  Parameters are a flat dict with the vendored class's
 state_dict keys: cls_token, pos_embed, patch_embed.proj.{weight,bias},

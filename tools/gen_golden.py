@@ -133,6 +133,8 @@ def main():
         gen_jigsaw()
     if not only or "jigsaw_modes" in only:
         gen_jigsaw_modes()
+    if not only or "timm" in only:
+        gen_timm_vit()
     if not only or "rollout" in only:
         gen_rollout()
     if not only or "grad_rollout" in only:
@@ -246,6 +248,116 @@ def gen_jigsaw_modes():
     out_path = os.path.join(OUT, "jigsaw_modes.npz")
     np.savez_compressed(out_path, **arr)
     print("jigsaw modes", len(keys), "bytes", os.path.getsize(out_path), "branches that raise in the reference:", failed)
+
+
+def _reference_timm_classes():
+    """VisionTransformer (with the reference's unk_mask changes), Block, Attention of tim/models/vision_transformer.py
+    and what their constructors call -- PatchEmbed, Mlp, DropPath, to_2tuple, Format, nchw_to, _assert, use_fused_attn --
+    from the reference's vendored tim/layers.  The packages themselves cannot be imported (tim/__init__ pulls
+    torchvision, and vision_transformer.py imports the pip package timm): the small self-contained files are loaded by
+    path, and of the others only the needed class / function definitions are compiled out of their files with ast.
+    Every line that runs is the reference's own text."""
+    import ast
+    import importlib.util
+    import logging
+    import math
+    import typing
+    from collections import OrderedDict
+    from functools import partial
+
+    import torch.nn.functional as F
+    from torch import nn
+    from torch.jit import Final
+    layers = os.path.join(REF, "tim", "layers")
+
+    def whole(name):
+        spec = importlib.util.spec_from_file_location("_ref_tim_" + name, os.path.join(layers, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    helpers, fmt, trace, config = whole("helpers"), whole("format"), whole("trace_utils"), whole("config")
+    ns = {"torch": torch, "nn": nn, "F": F, "partial": partial, "logging": logging, "math": math, "Final": Final,
+          "OrderedDict": OrderedDict, "to_2tuple": helpers.to_2tuple, "Format": fmt.Format, "nchw_to": fmt.nchw_to,
+          "_assert": trace._assert, "use_fused_attn": config.use_fused_attn}
+    ns.update({k: getattr(typing, k) for k in ("Callable", "List", "Optional", "Sequence", "Tuple", "Union", "Any")})
+
+    def defs(path, names):
+        tree = ast.parse(open(path).read(), filename=path)
+        body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+        assert sorted(n.name for n in body) == sorted(names), (path, names)
+        exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+
+    defs(os.path.join(layers, "drop.py"), ["drop_path", "DropPath"])
+    defs(os.path.join(layers, "mlp.py"), ["Mlp"])
+    defs(os.path.join(layers, "patch_embed.py"), ["PatchEmbed"])
+    defs(os.path.join(REF, "tim", "models", "vision_transformer.py"), ["Attention", "LayerScale", "Block", "VisionTransformer"])
+    return ns["VisionTransformer"]
+
+
+def gen_timm_vit():
+    """The reference's timm-style VisionTransformer with unk_mask (trainer.py:172-176 builds vit_small_patch16_224 of
+    this class) -> tests/golden/timm_*.npz: state_dict, inputs, logits, loss, every gradient, per-layer attention
+    probabilities (hooks on attn_drop with fused_attn off, as trainer.py:81-84 / vit_rollout.py:85-98 do) and the
+    token features, for token and avg pooling, masked and unmasked, heads of 16 and of 64."""
+    VisionTransformer = _reference_timm_classes()
+    torch.set_num_threads(1)
+    cases = {
+        "timm_token": (dict(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2, num_heads=4), 6, False),
+        "timm_token_mask": (dict(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2, num_heads=4), 6, True),
+        "timm_avg_mask": (dict(img_size=32, patch_size=4, num_classes=10, embed_dim=64, depth=2, num_heads=4,
+                               global_pool="avg"), 6, True),
+        "timm_dh64_n197": (dict(img_size=224, patch_size=16, num_classes=7, embed_dim=128, depth=1, num_heads=2), 2, True),
+    }
+    for name, (kw, B, masked) in cases.items():
+        torch.manual_seed(7)
+        m = VisionTransformer(weight_init="skip", **kw)
+        g = torch.Generator().manual_seed(11)
+        with torch.no_grad():                  # non-degenerate values everywhere
+            for pn, p in m.named_parameters():
+                if pn.endswith("bias") or "cls_token" in pn:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+                elif "norm" in pn and pn.endswith("weight"):
+                    p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g))
+                elif "pos_embed" in pn:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * p.shape[-1] ** -0.5)
+        for blk in m.blocks:
+            blk.attn.fused_attn = False        # trainer.py:81-84 switch_fused_attn
+        m.train()
+        arrays = {f"param/{k}": v.detach().numpy().copy() for k, v in m.state_dict().items()}
+        img = kw["img_size"]
+        L = (img // kw["patch_size"]) ** 2
+        x = torch.randn(B, 3, img, img, generator=g)
+        y = torch.randint(0, kw["num_classes"], (B,), generator=g)
+        unk = None
+        if masked:
+            unk = torch.zeros(1, L + 1, dtype=torch.long)
+            unk[0, torch.randperm(L, generator=g)[:L // 2] + 1] = 1
+        probs = []
+        hooks = [mod.register_forward_hook(lambda mm, i, o: probs.append(o.detach().clone()))
+                 for n_, mod in m.named_modules() if "attn_drop" in n_]
+        feats = m.forward_features(x, unk)
+        logits = m.forward_head(feats)
+        for h in hooks:
+            h.remove()
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        loss.backward()
+        arrays.update({"x": x.numpy(), "y": y.numpy(), "logits": logits.detach().numpy(), "loss": loss.detach().numpy(),
+                       "features": feats.detach().numpy()})
+        if unk is not None:
+            arrays["unk_mask"] = unk.numpy()
+        for i, pr in enumerate(probs):
+            arrays[f"probs/{i}"] = pr.numpy()
+        for pn, p in m.named_parameters():
+            arrays[f"grad/{pn}"] = p.grad.numpy()
+        arrays["cfg/heads"] = np.array(kw["num_heads"], dtype=np.int64)
+        arrays["cfg/pool"] = np.array(kw.get("global_pool", "token"))
+        arrays["cfg/kw"] = np.array(repr(kw))
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **arrays)
+        print(name, "loss", float(loss), "bytes", os.path.getsize(path))
 
 
 def _reference_functions(path, names):
