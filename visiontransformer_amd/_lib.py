@@ -42,6 +42,7 @@ SIGNATURES = {
     "vitmi_debug_set_nt_group": (I, [I]),
     "vitmi_debug_set_nt_tail_split": (I, [I]),
     "vitmi_debug_set_attn_head_groups": (I, [I]),
+    "vitmi_debug_set_attn_bwd_fused": (I, [I]),
     "vitmi_debug_set_gelu_pair": (I, [I]),
     "vitmi_debug_set_nt_stagger": (I, [I, I, I]),
     "vitmi_colsum_workspace_bytes": (L, [L, I]),

@@ -581,6 +581,635 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(NC
     }
 }
 
+// ================================================================ backward, one kernel (bf16, dh = 64, 129..208 tokens)
+// P and dS are computed ONCE per (query, key) instead of once in each of the two kernels above: five matrix products
+// per pair instead of seven, half the exponentials, and q, k, v, dO are fetched once.  A 16-wave workgroup holds the
+// Q, dO and K images of one (image, head) pair.  Waves 0 .. ceil(N/16)-1 own 16 keys each, exactly as in the dK/dV
+// kernel (K and V fragments in registers, S and dP with the KEY on the lane, dK^T and dV^T accumulated in
+// registers), and walk the query chunks in step.  dQ needs dS with the QUERY on the lane: each owner writes its
+// [16 keys x 32 queries] dS^T tile of the chunk into an LDS buffer, a barrier follows, and waves 13..15 then share
+// the eight 16 x 16 tiles of dQ^T of the chunk's 32 queries over ALL keys from that buffer
+// (transposed reads of the buffer and of the K image) while the owners go on to the next chunk and the other
+// buffer.  A chunk's dQ is complete after its own pass, so nothing is accumulated across waves: no atomics, and
+// the result does not depend on timing.
+constexpr int FUSED_THREADS = 1024;
+#ifndef VITMI_FUSED_ABL
+#define VITMI_FUSED_ABL 0
+#endif
+constexpr int FUSED_TASK_WAVE0 = 13;                 // waves 0..12 can own keys
+constexpr int FUSED_DQ_WAVE0 = 14;                   // waves 14, 15 compute dQ
+
+// dS^T chunk buffer: [keys][32 queries] bf16; 16-byte piece p of row r is stored at piece p ^ ((r >> 2) & 3), so that
+// the 16 rows of a tile write and the 4 x 32 bytes of a transposed read each cover distinct banks
+__device__ __forceinline__ int dsb_off(int row, int col) {
+    return row * 32 + ((((col >> 3) ^ (row >> 2)) & 3) << 3) + (col & 7);
+}
+// element j of lane (fr, fg) = buffer[seq0 + 8*fg + j][col0 + fr]
+__device__ __forceinline__ bf16x8 dsb_tr_frag(const bf16_t* buf, int seq0, int col0, int lane) {
+    const int fg = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int col = col0 + 4 * p;
+    const int r_lo = seq0 + 8 * fg + q, r_hi = r_lo + 4;
+    typedef __attribute__((address_space(3))) s16x4* lp;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(buf + dsb_off(r_lo, col)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(buf + dsb_off(r_hi, col)));
+    union {
+        s16x4 h[2];
+        bf16x8 v;
+    } u;
+    u.h[0] = lo;
+    u.h[1] = hi;
+    return u.v;
+}
+
+template <int NC>
+__global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_fused_bf16_kernel(const bf16_t* __restrict__ qkv,
+                                                                   const bf16_t* __restrict__ out,
+                                                                   const bf16_t* __restrict__ dout,
+                                                                   const float* __restrict__ lse,
+                                                                   bf16_t* __restrict__ dqkv, int N, int H, int npairs, float scale) {
+    constexpr int DH = 64;
+    using A = AttnDims<DH>;
+    constexpr int NP = NC * 32, IMG = NP * A::W, DSB = NP * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* dOs = Qs + IMG;
+    bf16_t* Ks = dOs + IMG;
+    bf16_t* dsb0 = Ks + IMG;                                  // two chunk buffers
+    float* lse2 = reinterpret_cast<float*>(dsb0 + 2 * DSB);   // [NP], then delta [NP]
+    float* delta = lse2 + NP;
+
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntk = (N + 15) >> 4;                            // the launcher guarantees ntk <= FUSED_TASK_WAVE0
+    const bool owner = wave < ntk;
+    const float sl2 = scale * LOG2E;
+    // rows of the chunk buffers that no owner writes must not hold NaN patterns: their K rows are zero
+    for (int i = threadIdx.x; i < 2 * DSB / 8; i += FUSED_THREADS) *reinterpret_cast<bf16x8*>(dsb0 + 8 * i) = zero8();
+
+    // a workgroup per compute unit walks the pairs base, base + G, ...: at any time an XCD works on a contiguous
+    // range of pairs (the heads of a few images)
+    for (int pair = xcd_block_order(); pair < npairs; pair += gridDim.x) {
+        const int b = pair / H, h = pair % H;
+        const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
+        const bf16_t* kb = qb + I;
+        const bf16_t* vb = qb + 2 * I;
+        const bf16_t* ob = out + (long long)b * N * I + h * DH;
+        const bf16_t* dob = dout + (long long)b * N * I + h * DH;
+        // everything derived from the thread index is formed again per pair: kept across the loop, the LDS offsets of
+        // the staging and of both phases would crowd out the accumulators
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+        const int key = wave * 16 + fr;
+
+        bf16x8 kf[A::KS], vf[A::KS];
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) {
+            kf[ks] = global_frag<DH>(kb, ld, owner ? key : N, N, ks, fg);
+            vf[ks] = global_frag<DH>(vb, ld, owner ? key : N, N, ks, fg);
+        }
+        for (int q = tid; q < NP; q += FUSED_THREADS)             // log2-unit lse; padded queries get p = 0
+            lse2[q] = q < N ? lse[((long long)b * H + h) * N + q] * LOG2E : 1e30f;
+        {
+            // Q, dO, K images; delta = rowsum(dO * O) from the same dO pieces (the 8 pieces of a row sit in 8 adjacent lanes)
+            constexpr int TOT = NP * A::CPR, IT = (TOT + FUSED_THREADS - 1) / FUSED_THREADS;
+            bf16x8 vq[IT], vk[IT], vd[IT], vo[IT];
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const int c = tid + i * FUSED_THREADS;
+                const int r = c / A::CPR, col = (c % A::CPR) * 8;
+                vq[i] = vk[i] = vd[i] = vo[i] = zero8();
+                if (c < TOT && r < N && !(VITMI_FUSED_ABL & 8)) {
+                    vq[i] = *reinterpret_cast<const bf16x8*>(qb + (long long)r * ld + col);
+                    vk[i] = *reinterpret_cast<const bf16x8*>(kb + (long long)r * ld + col);
+                    vd[i] = *reinterpret_cast<const bf16x8*>(dob + (long long)r * I + col);
+                    vo[i] = *reinterpret_cast<const bf16x8*>(ob + (long long)r * I + col);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < IT; ++i) {
+                const int c = tid + i * FUSED_THREADS;
+                const int r = c / A::CPR, kc = c % A::CPR;
+                float part = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) part += (float)vo[i][j] * (float)vd[i][j];
+                part += __shfl_xor(part, 1, 64);
+                part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 4, 64);
+                if (c < TOT) {
+                    *reinterpret_cast<bf16x8*>(Qs + img_off<DH>(r, kc)) = vq[i];
+                    *reinterpret_cast<bf16x8*>(Ks + img_off<DH>(r, kc)) = vk[i];
+                    *reinterpret_cast<bf16x8*>(dOs + img_off<DH>(r, kc)) = vd[i];
+                    if (kc == 0) delta[r] = part;
+                }
+            }
+        }
+        __syncthreads();
+
+        if (wave < FUSED_DQ_WAVE0) {
+            // ---- key owners (and the spare wave, which only keeps the barriers): dK^T, dV^T, and the chunk's dS^T tile
+            f32x4 dkt[A::DT], dvt[A::DT];
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) dkt[dt] = dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int c = 0; c < NC; ++c) {
+                bf16_t* dsb = dsb0 + (c & 1) * DSB;
+                if (owner && !(VITMI_FUSED_ABL & 2)) {
+                    bf16x8 pf, dsf;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int qrow = perm_row(c, u, fr);
+                        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < A::KS; ++ks) {
+                            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(Qs, qrow, ks, fg), kf[ks], sa, 0, 0, 0);
+                            dpa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(dOs, qrow, ks, fg), vf[ks], dpa, 0, 0, 0);
+                        }
+                        const int q0 = 32 * c + 8 * fg + 4 * u;     // this lane's rows are queries q0 + r
+                        const f32x4 l2 = *reinterpret_cast<const f32x4*>(&lse2[q0]);
+                        const f32x4 dl = *reinterpret_cast<const f32x4*>(&delta[q0]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -l2[r]));
+                            pf[4 * u + r] = (bf16_t)p;
+                            dsf[4 * u + r] = (bf16_t)(p * (dpa[r] - dl[r]));     // the 1/sqrt(dh) goes onto the finished dK, dQ
+                        }
+                    }
+                    // element j is query 32c + 8fg + j of key `key`; keys past N must not reach dQ
+                    *reinterpret_cast<bf16x8*>(dsb + dsb_off(key, 8 * fg)) = key < N ? dsf : zero8();
+#pragma unroll
+                    for (int dt = 0; dt < A::DT; ++dt) {
+                        dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(dOs, 32 * c, dt * 16, lane), pf, dvt[dt],
+                                                                          0, 0, 0);
+                        dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Qs, 32 * c, dt * 16, lane), dsf, dkt[dt],
+                                                                          0, 0, 0);
+                    }
+                }
+                // the chunk's LDS writes are done and visible; stores to HBM still in flight are not waited for
+                if (!(VITMI_FUSED_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if (owner && key < N) {
+                bf16_t* dk = dqkv + ((long long)b * N + key) * ld + I + h * DH;
+                bf16_t* dv = dk + I;
+#pragma unroll
+                for (int dt = 0; dt < A::DT; ++dt) {
+                    const int d = dt * 16 + fg * 4;
+                    bf16x4 a, c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        a[r] = (bf16_t)(dkt[dt][r] * scale);
+                        c[r] = (bf16_t)dvt[dt][r];
+                    }
+                    *reinterpret_cast<bf16x4*>(dk + d) = a;
+                    *reinterpret_cast<bf16x4*>(dv + d) = c;
+                }
+            }
+        } else {
+            // ---- dQ^T of each chunk, [64 head dim x 32 queries], behind the chunk's barrier: each of the two waves
+            // takes a 32 x 32 block (two head-dim tiles x two query halves), K^T fragments times dS^T fragments over the
+            // key chunks, the fragments of key chunk kc + 1 requested before the products of kc
+            const int tw = wave - FUSED_DQ_WAVE0;
+            // the owners wait for these two waves at the next barrier: they go first wherever they share a SIMD
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll 1
+            for (int c = 0; c < NC; ++c) {
+                const bf16_t* dsb = dsb0 + (c & 1) * DSB;
+                if (!(VITMI_FUSED_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (VITMI_FUSED_ABL & 1) continue;
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 ka[2][2], sb[2][2];        // [stage][head-dim tile], [stage][query half]
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ka[0][i] = tr_frag<DH>(Ks, 0, (2 * tw + i) * 16, lane);
+                    sb[0][i] = dsb_tr_frag(dsb, 0, 16 * i, lane);
+                }
+#pragma unroll
+                for (int kc = 0; kc < NC; ++kc) {
+                    if (kc + 1 < NC) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            ka[(kc + 1) & 1][i] = tr_frag<DH>(Ks, 32 * (kc + 1), (2 * tw + i) * 16, lane);
+                            sb[(kc + 1) & 1][i] = dsb_tr_frag(dsb, 32 * (kc + 1), 16 * i, lane);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kc & 1][i], sb[kc & 1][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = 32 * c + 16 * j + fr;
+                    if (q < N) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            bf16x4 v;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[i][j][r] * scale);
+                            *reinterpret_cast<bf16x4*>(dqkv + ((long long)b * N + q) * ld + h * DH + (2 * tw + i) * 16 + fg * 4) = v;
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // the images are rewritten for the next pair: the last chunk's dQ must be through with them
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+}
+
+// ---------------------------------------------------------------- the same, pipelined across pairs (193..208 tokens)
+// A workgroup fills its compute unit, so nothing else hides the time its operands take to arrive: here they are
+// fetched one pair ahead.  The Q and dO images (and lse, delta) exist twice; at the first chunk of pair i every wave
+// requests its share of the Q and dO images of pair i+1 straight into the other set (direct-to-LDS loads: no
+// registers, so all 52 KB are in flight at once), the O pieces follow through registers and meet the landed dO
+// image five chunks later to give delta.  The K image is read by the dQ waves up to the last chunk, so the next K
+// travels in registers over the last two chunks and is written behind the barrier that ends the pair; the owners'
+// K and V fragments of the next pair are requested as
+// soon as the last chunk's score products have used the old ones.  Images hold 208 rows (13 key tiles): the last
+// query chunk reads 16 rows past an image, which are finite values of the neighbouring image and meet
+// probabilities that are exactly zero; the dQ product masks the key rows past 208 instead.
+constexpr int PIPE_NC = 7, PIPE_ROWS = 208, PIPE_NQ = PIPE_NC * 32;
+constexpr int PIPE_LAND = PIPE_NC - 3;               // the chunk by whose end the next pair's Q and dO images have landed
+__device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4] = {0u, 0u, 0u, 0u};   // source of the pieces of rows past N
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+constexpr size_t PIPE_LDS = (size_t)5 * PIPE_ROWS * 64 * 2 + (size_t)2 * PIPE_ROWS * 32 * 2 + (size_t)4 * PIPE_NQ * 4;
+
+__global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const bf16_t* __restrict__ qkv,
+                                                                  const bf16_t* __restrict__ out,
+                                                                  const bf16_t* __restrict__ dout,
+                                                                  const float* __restrict__ lse,
+                                                                  bf16_t* __restrict__ dqkv, int N, int H, int npairs,
+                                                                  float scale) {
+    constexpr int DH = 64, NC = PIPE_NC, ROWS = PIPE_ROWS, NQ = PIPE_NQ;
+    using A = AttnDims<DH>;
+    constexpr int IMG = ROWS * A::W, DSB = ROWS * 32, PCS = ROWS * A::CPR;   // PCS: 16-byte pieces of an image
+    static_assert(ROWS % 8 == 0 && 2 * (ROWS / 8) == 4 * FUSED_TASK_WAVE0 && PCS <= 2 * FUSED_THREADS && PIPE_LAND >= 0,
+                  "the fetch schedule below assumes these");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* img0 = reinterpret_cast<bf16_t*>(smem);          // [Q set 0][dO set 0][Q set 1][dO set 1][K]
+    bf16_t* Ks = img0 + 4 * IMG;
+    bf16_t* dsb0 = Ks + IMG;                                  // two chunk buffers of dS^T
+    float* lsd = reinterpret_cast<float*>(dsb0 + 2 * DSB);    // [set][lse in log2 units | delta][NQ]
+
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntk = (N + 15) >> 4;                            // <= 13
+    const bool owner = wave < ntk;
+    const float sl2 = scale * LOG2E;
+    const int G = gridDim.x;
+
+    // every byte of LDS starts finite: rows that are only ever read past an image, chunk-buffer rows no owner writes
+    for (int i = threadIdx.x; i < (int)(PIPE_LDS / 16); i += FUSED_THREADS) *reinterpret_cast<bf16x8*>(img0 + 8 * i) = zero8();
+    __syncthreads();
+
+    int pair = xcd_block_order();
+    bf16x8 kf[A::KS], vf[A::KS];
+    if (pair < npairs) {
+        // the first pair arrives the plain way: all four matrices at once
+        const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+        const int b = pair / H, h = pair % H;
+        const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
+        const bf16_t* ob = out + (long long)b * N * I + h * DH;
+        const bf16_t* dob = dout + (long long)b * N * I + h * DH;
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) {
+            kf[ks] = global_frag<DH>(qb + I, ld, owner ? wave * 16 + fr : N, N, ks, fg);
+            vf[ks] = global_frag<DH>(qb + 2 * I, ld, owner ? wave * 16 + fr : N, N, ks, fg);
+        }
+        if (tid < NQ) lsd[tid] = tid < N ? lse[((long long)b * H + h) * N + tid] * LOG2E : 1e30f;
+        bf16x8 vq[2], vk[2], vd[2], vo[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * FUSED_THREADS;
+            const int r = c >> 3, col = (c & 7) * 8;
+            vq[i] = vk[i] = vd[i] = vo[i] = zero8();
+            if (c < PCS && r < N) {
+                vq[i] = *reinterpret_cast<const bf16x8*>(qb + (long long)r * ld + col);
+                vk[i] = *reinterpret_cast<const bf16x8*>(qb + I + (long long)r * ld + col);
+                vd[i] = *reinterpret_cast<const bf16x8*>(dob + (long long)r * I + col);
+                vo[i] = *reinterpret_cast<const bf16x8*>(ob + (long long)r * I + col);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * FUSED_THREADS;
+            const int r = c >> 3, kc = c & 7;
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)vo[i][j] * (float)vd[i][j];
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            part += __shfl_xor(part, 4, 64);
+            if (c < PCS) {
+                *reinterpret_cast<bf16x8*>(img0 + img_off<DH>(r, kc)) = vq[i];
+                *reinterpret_cast<bf16x8*>(img0 + IMG + img_off<DH>(r, kc)) = vd[i];
+                *reinterpret_cast<bf16x8*>(Ks + img_off<DH>(r, kc)) = vk[i];
+                if (kc == 0) lsd[NQ + r] = part;
+            }
+        }
+    }
+    __syncthreads();
+
+    // per pair: where the next pair's operands come from, which LDS set is read and which is filled
+    struct Ctx {
+        int b, h;
+        bool has_next;
+        const bf16_t *qn, *on, *don;          // next pair: q (k = +I, v = +2I), O, dO
+        const float* lsen;
+        const bf16_t *Qs, *dOs;
+        bf16_t *Qn, *dOn;
+        const float *lse2, *delta;
+        float *lse2n, *deltan;
+    };
+    auto make_ctx = [&](int pair, int cur) {
+        Ctx x;
+        x.b = pair / H;
+        x.h = pair % H;
+        x.has_next = pair + G < npairs;
+        const int nb = (pair + G) / H, nh = (pair + G) % H;
+        x.qn = qkv + (long long)nb * N * ld + nh * DH;
+        x.on = out + (long long)nb * N * I + nh * DH;
+        x.don = dout + (long long)nb * N * I + nh * DH;
+        x.lsen = lse + ((long long)nb * H + nh) * N;
+        x.Qs = img0 + cur * 2 * IMG;
+        x.dOs = x.Qs + IMG;
+        x.Qn = img0 + (cur ^ 1) * 2 * IMG;
+        x.dOn = x.Qn + IMG;
+        x.lse2 = lsd + cur * 2 * NQ;
+        x.delta = x.lse2 + NQ;
+        x.lse2n = lsd + (cur ^ 1) * 2 * NQ;
+        x.deltan = x.lse2n + NQ;
+        return x;
+    };
+    // a thread's two pieces of the next K image: requested at the start of chunk NC - 2, kept in registers until the
+    // pair's last barrier, when the dQ waves are through with the present image
+    auto fetch_k = [&](const Ctx& x, int tid, bf16x8& kp0, bf16x8& kp1) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));              // addresses are formed where they are used, not ahead of the chunk loop
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = i * FUSED_THREADS + tl, r = p >> 3, col = (p & 7) * 8;
+            bf16x8 v = zero8();
+            if (p < PCS && r < N) v = *reinterpret_cast<const bf16x8*>(x.qn + I + (long long)r * ld + col);
+            if (i == 0) kp0 = v; else kp1 = v;
+        }
+    };
+    auto commit_k = [&](int tid, const bf16x8& kp0, const bf16x8& kp1) {
+        int tl = tid;
+        asm volatile("" : "+v"(tl));
+        *reinterpret_cast<bf16x8*>(Ks + img_off<DH>(tl >> 3, tl & 7)) = kp0;
+        const int p1 = FUSED_THREADS + tl;
+        if (p1 < PCS) *reinterpret_cast<bf16x8*>(Ks + img_off<DH>(p1 >> 3, p1 & 7)) = kp1;
+    };
+
+    if (wave < FUSED_TASK_WAVE0) {
+        // ================= waves 0..12: key owners (a wave past ceil(N/16) only fetches and keeps the barriers)
+        int cur = 0;
+        for (; pair < npairs; pair += G, cur ^= 1) {
+            const Ctx x = make_ctx(pair, cur);
+            // everything derived from the thread index is formed again per pair: kept across the loop, the LDS offsets
+            // would crowd out the accumulators
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            tid &= FUSED_THREADS - 1;
+            const int lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+            const int key = wave * 16 + fr;
+            bf16x8 kp0 = zero8(), kp1 = zero8();
+            f32x4 dkt[A::DT], dvt[A::DT];
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) dkt[dt] = dvt[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int c = 0; c < NC; ++c) {
+                bf16_t* dsb = dsb0 + (c & 1) * DSB;
+                if (c == NC - 2 && x.has_next) fetch_k(x, tid, kp0, kp1);
+                if (owner) {
+                    bf16x8 pf, dsf;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int qrow = perm_row(c, u, fr);
+                        f32x4 sa = {0.f, 0.f, 0.f, 0.f}, dpa = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ks = 0; ks < A::KS; ++ks) {
+                            sa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(x.Qs, qrow, ks, fg), kf[ks], sa, 0, 0, 0);
+                            dpa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag<DH>(x.dOs, qrow, ks, fg), vf[ks], dpa, 0, 0, 0);
+                        }
+                        const int q0 = 32 * c + 8 * fg + 4 * u;     // this lane's rows are queries q0 + r
+                        const f32x4 l2 = *reinterpret_cast<const f32x4*>(&x.lse2[q0]);
+                        const f32x4 dl = *reinterpret_cast<const f32x4*>(&x.delta[q0]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float p = __builtin_amdgcn_exp2f(fmaf(sa[r], sl2, -l2[r]));
+                            pf[4 * u + r] = (bf16_t)p;
+                            dsf[4 * u + r] = (bf16_t)(p * (dpa[r] - dl[r]));     // the 1/sqrt(dh) goes onto the finished dK, dQ
+                        }
+                    }
+                    if (c == NC - 1 && x.has_next) {
+                        // the old fragments have served their last product
+#pragma unroll
+                        for (int ks = 0; ks < A::KS; ++ks) {
+                            kf[ks] = global_frag<DH>(x.qn + I, ld, key, N, ks, fg);
+                            vf[ks] = global_frag<DH>(x.qn + 2 * I, ld, key, N, ks, fg);
+                        }
+                    }
+                    // element j is query 32c + 8fg + j of key `key`; keys past N must not reach dQ
+                    *reinterpret_cast<bf16x8*>(dsb + dsb_off(key, 8 * fg)) = key < N ? dsf : zero8();
+#pragma unroll
+                    for (int dt = 0; dt < A::DT; ++dt) {
+                        dvt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(x.dOs, 32 * c, dt * 16, lane), pf, dvt[dt],
+                                                                          0, 0, 0);
+                        dkt[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(x.Qs, 32 * c, dt * 16, lane), dsf, dkt[dt],
+                                                                          0, 0, 0);
+                    }
+                }
+                if (c == 0 && x.has_next) {
+                    // the next pair's Q and dO images, straight into LDS: 52 blocks of 8 rows, four per wave.  The loads
+                    // are issued outside the compiler's view, so no LDS read is made to wait for them; this wave waits
+                    // for them itself at the end of chunk PIPE_LAND.  They follow the chunk's products because the wait for
+                    // the K and V fragments, requested at the end of the pair before, would otherwise wait for them too.
+                    int ll = lane;
+                    asm volatile("" : "+v"(ll));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int j = wave * 4 + k;                        // Q blocks, then dO blocks
+                        const bool isq = j < ROWS / 8;
+                        const int blk = isq ? j : j - ROWS / 8;
+                        const int r = blk * 8 + (ll >> 3);
+                        const int kc = (ll & 7) ^ img_swz<DH>(r);          // the piece that belongs at this lane's place
+                        const bf16_t* src = isq ? x.qn + (long long)r * ld + kc * 8 : x.don + (long long)r * I + kc * 8;
+                        const void* from = r < N ? (const void*)src : (const void*)g_attn_zero16;
+                        const unsigned to = (unsigned)(unsigned long long)(lds_ptr_t)((isq ? x.Qn : x.dOn) + blk * 8 * A::W);
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(from), "s"(to) : "memory");
+                    }
+                }
+                // chunk PIPE_LAND ends with this wave's direct-to-LDS loads landed (nothing else of its own is in flight)
+                if (c == PIPE_LAND && x.has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the chunk's LDS writes are done and visible; stores to HBM still in flight are not waited for
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if (owner && key < N) {
+                bf16_t* dk = dqkv + ((long long)x.b * N + key) * ld + I + x.h * DH;
+                bf16_t* dv = dk + I;
+#pragma unroll
+                for (int dt = 0; dt < A::DT; ++dt) {
+                    const int d = dt * 16 + fg * 4;
+                    bf16x4 a, c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        a[r] = (bf16_t)(dkt[dt][r] * scale);
+                        c[r] = (bf16_t)dvt[dt][r];
+                    }
+                    *reinterpret_cast<bf16x4*>(dk + d) = a;
+                    *reinterpret_cast<bf16x4*>(dv + d) = c;
+                }
+            }
+            // the last chunk's dQ is through with the K image: the next one goes in
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (x.has_next) commit_k(tid, kp0, kp1);
+        }
+    } else {
+        // ================= helper waves 13..15.  All three fetch what needs arithmetic on the way: the next pair's O
+        // and dO pieces, two of each per thread and chunk, whose products give delta = rowsum(dO * O), and lse.
+        // Waves 14, 15 also compute dQ^T of chunk c - 1, [64 head dim x 32 queries], beside the owners' chunk c: each
+        // takes a 32 x 32 block (two head-dim tiles x two query halves), K^T fragments times dS^T fragments over the
+        // key chunks, the fragments of key chunk kc + 1 requested before the products of kc.
+        constexpr int HT = FUSED_THREADS - FUSED_TASK_WAVE0 * 64;          // helper threads: 192
+        constexpr int RP = 2;                                              // pieces per thread and round
+        static_assert(RP * HT * (NC - 2) >= PCS && NQ <= 2 * HT, "NC - 2 rounds cover an image");
+        const int tw = wave - FUSED_DQ_WAVE0;
+        int cur = 0;
+        for (; pair < npairs; pair += G, cur ^= 1) {
+            const Ctx x = make_ctx(pair, cur);
+            int tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            tid &= FUSED_THREADS - 1;
+            const int lane = tid & 63, fr = lane & 15, fg = lane >> 4;
+            const int ht = tid - FUSED_TASK_WAVE0 * 64;
+            bf16x8 kp0 = zero8(), kp1 = zero8();
+            bf16x8 ro[RP], rd[RP];                 // a round's O pieces and the dO pieces of the same places
+            float lv[2] = {0.f, 0.f};
+            // round k (requested at the start of chunk k, used at the start of chunk k + 1): pieces ht + (RP k + i) HT
+            auto round_load = [&](int k) {
+                int hl = ht;
+                asm volatile("" : "+v"(hl));
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const int p = hl + (RP * k + i) * HT, r = p >> 3, col = (p & 7) * 8;
+                    ro[i] = rd[i] = zero8();
+                    if (p < PCS && r < N) {
+                        ro[i] = *reinterpret_cast<const bf16x8*>(x.on + (long long)r * I + col);
+                        rd[i] = *reinterpret_cast<const bf16x8*>(x.don + (long long)r * I + col);
+                    }
+                }
+            };
+            auto round_use = [&](int k) {
+                int hl = ht;
+                asm volatile("" : "+v"(hl));
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const int p = hl + (RP * k + i) * HT, r = p >> 3, kc = p & 7;
+                    float part = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) part += (float)ro[i][j] * (float)rd[i][j];
+                    part += __shfl_xor(part, 1, 64);       // a row's 8 pieces are 8 adjacent lanes
+                    part += __shfl_xor(part, 2, 64);
+                    part += __shfl_xor(part, 4, 64);
+                    if (p < PCS && kc == 0) x.deltan[r] = part;
+                }
+            };
+            auto dq_chunk = [&](int c) {
+                const bf16_t* dsb = dsb0 + (c & 1) * DSB;
+                int ln = lane;
+                asm volatile("" : "+v"(ln));      // fragment addresses are formed per chunk, not kept across the loop
+                ln &= 63;
+                f32x4 acc[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 ka[2][2], sb[2][2];        // [stage][head-dim tile], [stage][query half]
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ka[0][i] = tr_frag<DH>(Ks, 0, (2 * tw + i) * 16, ln);
+                    sb[0][i] = dsb_tr_frag(dsb, 0, 16 * i, ln);
+                }
+#pragma unroll
+                for (int kc = 0; kc < NC; ++kc) {
+                    if (kc + 1 < NC) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            ka[(kc + 1) & 1][i] = tr_frag<DH>(Ks, 32 * (kc + 1), (2 * tw + i) * 16, ln);
+                            sb[(kc + 1) & 1][i] = dsb_tr_frag(dsb, 32 * (kc + 1), 16 * i, ln);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (32 * (kc + 1) > ROWS) {
+                        // element j of the fragment is key row 32 kc + 8 fg + j: rows past the buffer count as zero
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) sb[kc & 1][j] = keep_first(sb[kc & 1][j], ROWS - 32 * kc - 8 * (ln >> 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[kc & 1][i], sb[kc & 1][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int q = 32 * c + 16 * j + fr;
+                    if (q < N) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            bf16x4 v;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[i][j][r] * scale);
+                            *reinterpret_cast<bf16x4*>(dqkv + ((long long)x.b * N + q) * ld + x.h * DH + (2 * tw + i) * 16 + fg * 4) = v;
+                        }
+                    }
+                }
+            };
+            // the owners wait for these waves at the next barrier: they go first wherever they share a SIMD
+            __builtin_amdgcn_s_setprio(3);
+#pragma unroll 1
+            for (int c = 0; c < NC; ++c) {
+                if (x.has_next) {
+                    if (c > 0 && c <= NC - 2) round_use(c - 1);
+                    if (c == 0) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            if (ht + i * HT < N) lv[i] = x.lsen[ht + i * HT];
+                    } else if (c == 1) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const int q = ht + i * HT;
+                            if (q < NQ) x.lse2n[q] = q < N ? lv[i] * LOG2E : 1e30f;
+                        }
+                    }
+                    if (c < NC - 2) round_load(c);
+                    if (c == NC - 2) fetch_k(x, tid, kp0, kp1);
+                }
+                if (c > 0 && tw >= 0) dq_chunk(c - 1);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if (tw >= 0) dq_chunk(NC - 1);
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (x.has_next) commit_k(tid, kp0, kp1);
+        }
+    }
+}
+
 // ================================================================ fp32 path
 // forward: block per (b,h), K and V in LDS, one wave per query row.
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
@@ -907,6 +1536,51 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     return launch_bwd_t<DH, NC, 1>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
 }
 
+// one-kernel backward: heads of 64, 129..208 tokens (9..13 key tiles: the owners, with waves 13..15 on dQ)
+int g_attn_bwd_fused = 0;
+inline bool use_fused_bwd(int N, int DH) { return g_attn_bwd_fused && DH == 64 && N > 128 && N <= 16 * FUSED_TASK_WAVE0; }
+
+template <int NC>
+int launch_bwd_fused_t(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N,
+                       int H, hipStream_t s) {
+    const float scale = 1.0f / sqrtf(64.f);
+    static unsigned long long done = 0;
+    constexpr int NP = NC * 32;
+    const size_t sm = (size_t)NP * (3 * 64 * sizeof(bf16_t) + 2 * 32 * sizeof(bf16_t) + 2 * sizeof(float)) + 16;
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_fused_bf16_kernel<NC>), sm, &done, "vitmi_attn_bwd: LDS attribute (fused)");
+    if (rc != VITMI_OK) return rc;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    const int grid = B * H < cus ? B * H : cus;     // one workgroup fills a compute unit
+    hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<NC>), dim3(grid), dim3(FUSED_THREADS), sm, s, (const bf16_t*)qkv,
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, B * H, scale);
+    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(fused, bf16)");
+    return VITMI_OK;
+}
+int launch_bwd_pipe(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N, int H,
+                    hipStream_t s) {
+    const float scale = 1.0f / sqrtf(64.f);
+    static unsigned long long done = 0;
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_pipe_bf16_kernel), PIPE_LDS, &done, "vitmi_attn_bwd: LDS attribute (pipelined)");
+    if (rc != VITMI_OK) return rc;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    const int grid = B * H < cus ? B * H : cus;     // one workgroup fills a compute unit
+    hipLaunchKernelGGL(attn_bwd_pipe_bf16_kernel, dim3(grid), dim3(FUSED_THREADS), PIPE_LDS, s, (const bf16_t*)qkv,
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, B * H, scale);
+    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(pipelined, bf16)");
+    return VITMI_OK;
+}
+int launch_bwd_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int B, int N, int H,
+                     hipStream_t s) {
+    if (g_attn_bwd_fused == 2 && N > 32 * (PIPE_NC - 1) && N <= PIPE_ROWS) return launch_bwd_pipe(qkv, out, dout, lse, dqkv, B, N, H, s);
+    switch ((N + 31) / 32) {
+        case 5: return launch_bwd_fused_t<5>(qkv, out, dout, lse, dqkv, B, N, H, s);
+        case 6: return launch_bwd_fused_t<6>(qkv, out, dout, lse, dqkv, B, N, H, s);
+        default: return launch_bwd_fused_t<7>(qkv, out, dout, lse, dqkv, B, N, H, s);
+    }
+}
+
 #define DISPATCH_NC(FN, DH, ...)                      \
     switch (nc) {                                     \
         case 1: return FN<DH, 1>(__VA_ARGS__);        \
@@ -954,6 +1628,11 @@ int check_common(const char* who, int dt, int B, int N, int H, int DH) {
 
 extern "C" int vitmi_debug_set_attn_head_groups(int on) {
     g_attn_head_groups = on;
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_debug_set_attn_bwd_fused(int on) {
+    g_attn_bwd_fused = on;
     return VITMI_OK;
 }
 
@@ -1076,6 +1755,7 @@ static int attn_bwd_from_dout(const void* qkv, const void* out, const void* dout
     const int nc = pick_nc(N);
     VITMI_CHECK_ARG(workspace, "vitmi_attn_bwd: needs the workspace of vitmi_attn_bwd_workspace_bytes");
     float* delta = (float*)workspace;               // [B, H, N] fp32
+    if (use_fused_bwd(N, DH)) return launch_bwd_fused(qkv, out, dout, lse, dqkv, B, N, H, s);
     if (nc > 8) DISPATCH_NC_LONG(launch_bwd, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
     switch (DH) {
         case 8: DISPATCH_NC(launch_bwd, 8, qkv, out, dout, lse, delta, dqkv, B, N, H, s)
