@@ -137,8 +137,10 @@ int vitmi_debug_set_nt_tail_split(int on);
  * adjacent heads of an image when the head count is a multiple of six; 0: one (image, head) pair per workgroup for
  * every shape.  Same results bit for bit.  Process-wide; benchmarking. */
 int vitmi_debug_set_attn_head_groups(int on);
-/* 1: the bf16 attention backward for heads of 64 and 129..208 tokens runs as ONE kernel (P and dS computed once per
- * pair; dS goes through LDS to the dQ product); 0: the dQ kernel and the dK/dV kernel.  Process-wide; benchmarking. */
+/* The bf16 attention backward for heads of 64 and 129..208 tokens.  1: ONE kernel (P and dS computed once per pair;
+ * dS goes through LDS to the dQ product); 2 (default): the same, and with 193..208 tokens the variant that fetches
+ * the next pair's operands under the current pair's products; 0: the dQ kernel and the dK/dV kernel, as for every
+ * other shape.  Process-wide; benchmarking. */
 int vitmi_debug_set_attn_bwd_fused(int on);
 /* same for the weight-gradient (tn) GEMM: 0 = 128x128, 1 = 256x256, -1 = automatic */
 int vitmi_debug_set_tn_config(int cfg);

@@ -274,6 +274,32 @@ def test_attention_head_groups_bf16(ops, B, N, H, DH):
     assert all(torch.equal(a, b) for a, b in zip(got[1], got[0]))
 
 
+@pytest.mark.parametrize("B,N,H,DH", [(40, 197, 12, 64), (3, 129, 2, 64), (5, 160, 3, 64), (2, 192, 2, 64),
+                                      (90, 193, 3, 64), (2, 208, 5, 64), (1, 200, 1, 64)])
+def test_attention_backward_one_kernel_bf16(ops, B, N, H, DH):
+    # heads of 64 with 129..208 tokens: the backward runs as ONE kernel (attn_bwd_fused_bf16_kernel; with 193..208
+    # tokens attn_bwd_pipe_bf16_kernel, which fetches the next pair under the current one; more pairs than compute
+    # units make a workgroup walk several).  Each variant and the dQ + dK/dV pair against the fp32 expression.
+    from visiontransformer_amd._lib import lib
+    dtype = torch.bfloat16
+    qkv = rnd(B, N, 3 * H * DH, seed=7, scale=1.5)
+    do = rnd(B, N, H * DH, seed=8)
+    qr = q(qkv, dtype).requires_grad_(True)
+    o_ref, _, _ = attn_ref(qr, H, DH)
+    o_ref.backward(q(do, dtype))
+    qd, dod = qkv.to(DEV, dtype), do.to(DEV, dtype)
+    o, lse, _ = ops.attn_fwd(qd, B, N, H, DH, False)
+    try:
+        for mode in (0, 1, 2):
+            lib.vitmi_debug_set_attn_bwd_fused(mode)
+            dqkv = ops.attn_bwd(qd, o, dod, lse, B, N, H, DH).clone()
+            again = ops.attn_bwd(qd, o, dod, lse, B, N, H, DH)
+            assert torch.equal(dqkv, again), f"mode {mode}: two calls differ"
+            assert rel_err(dqkv, qr.grad) < TOL[dtype], f"mode {mode}"
+    finally:
+        lib.vitmi_debug_set_attn_bwd_fused(2)
+
+
 def test_attention_rejects_long_sequences(ops):
     from visiontransformer_amd._lib import VitmiError
     with pytest.raises(VitmiError, match="not supported"):

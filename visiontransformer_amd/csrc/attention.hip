@@ -1536,8 +1536,10 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     return launch_bwd_t<DH, NC, 1>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
 }
 
-// one-kernel backward: heads of 64, 129..208 tokens (9..13 key tiles: the owners, with waves 13..15 on dQ)
-int g_attn_bwd_fused = 0;
+// one-kernel backward: heads of 64, 129..208 tokens (9..13 key tiles: the owners, with waves 13..15 on dQ).
+// 0 = the dQ + dK/dV pair, 1 = one kernel, 2 = one kernel, operands of the next pair fetched under the current one
+// where that variant applies (193..208 tokens).  At B 256 / N 197 / H 12: 260 / 231 / 214 us per launch.
+int g_attn_bwd_fused = 2;
 inline bool use_fused_bwd(int N, int DH) { return g_attn_bwd_fused && DH == 64 && N > 128 && N <= 16 * FUSED_TASK_WAVE0; }
 
 template <int NC>
