@@ -115,6 +115,20 @@ long long vitmi_gemm_wgrad_workspace_bytes(int dt, int P, int Q, int T);
 int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv,
                      float* C, long long ldc, void* workspace, void* stream);
 
+/* Two weight gradients over the SAME T tokens, C0 [P0,Q0] = U0^T V0 and C1 [P1,Q1] = U1^T V1 (both dense fp32):
+ * the two nn.Linear weight gradients of one pre-norm sub-block (mymodel/ViT.py:66,69 resp. :86,89), which autograd
+ * computes as two GEMMs.  In bf16 with every extent a multiple of 256 and T a multiple of 64 both run in ONE launch
+ * that fills the compute units once (token slabs per output tile plus a shared remainder, fixed-order sum of the
+ * partial tiles: deterministic); any other case is two vitmi_gemm_wgrad calls.  workspace:
+ * vitmi_gemm_wgrad_pair_workspace_bytes. */
+long long vitmi_gemm_wgrad_pair_workspace_bytes(int dt, int T, int P0, int Q0, int P1, int Q1);
+int vitmi_gemm_wgrad_pair(int dt, int T, int P0, int Q0, const void* U0, long long ldu0, const void* V0,
+                          long long ldv0, float* C0, int P1, int Q1, const void* U1, long long ldu1, const void* V1,
+                          long long ldv1, float* C1, void* workspace, void* stream);
+/* 1 (default): vitmi_gemm_wgrad_pair may use the one-launch form; 0: always two launches.  Process-wide;
+ * benchmarking. */
+int vitmi_debug_set_tn_batch(int on);
+
 /* Tuning hook: force the block-tile configuration of the aligned nt GEMM (0 = 128x128, 1 = 256x128,
  * 2 = 256x256; -1 = automatic).  Process-wide; for benchmarking only. */
 int vitmi_debug_set_nt_config(int cfg);

@@ -121,6 +121,36 @@ def test_phased_weight_gradient_gemm_at_bench_shapes(ops, T, P, Q):
     assert torch.equal(dw, ops.linear_bwd_w(dy.to(DEV, BF), x.to(DEV, BF)))
 
 
+@pytest.mark.parametrize("T,Pa,Qa,Pb,Qb", [
+    (M_BENCH, 768, 3072, 3072, 768),       # MLP pair: 72 output tiles, three slabs each and a shared remainder
+    (M_BENCH, 768, 768, 2304, 768),        # attention pair: 36 tiles, seven equal slabs
+    (12608, 768, 3072, 3072, 768),         # 197 token tiles
+    (64 * 37, 256, 512, 512, 256),         # 4 tiles, 37 token tiles: slabs capped by the token count
+    (64 * 100, 768, 1024, 1280, 768),      # 27 tiles: nine slabs and a remainder over 13 blocks
+    (M_BENCH - 100, 768, 768, 2304, 768),  # tokens not a multiple of 64: two single launches
+    (6400, 768, 200, 2304, 768),           # an extent that is no multiple of 256: two single launches
+])
+def test_weight_gradient_pair(ops, T, Pa, Qa, Pb, Qb):
+    """linear_bwd_w_pair -> gemm_tn_batch_kernel + tn_batch_reduce_kernel (or two single products) against the fp64
+    product of the bf16-rounded operands, bit-identical on a second call and with the one-launch form switched off
+    to 1e-6 (other summation order)."""
+    from visiontransformer_amd._lib import lib
+    dya, xa, dyb, xb = rnd(T, Pa, seed=11), rnd(T, Qa, seed=12), rnd(T, Pb, seed=13), rnd(T, Qb, seed=14)
+    args = [t.to(DEV, BF) for t in (dya, xa, dyb, xb)]
+    dwa, dwb = ops.linear_bwd_w_pair(*args)
+    assert rel_err(dwa, q(dya).double().t() @ q(xa).double()) < 1e-4
+    assert rel_err(dwb, q(dyb).double().t() @ q(xb).double()) < 1e-4
+    dwa2, dwb2 = ops.linear_bwd_w_pair(*args)
+    assert torch.equal(dwa, dwa2) and torch.equal(dwb, dwb2)
+    try:
+        lib.vitmi_debug_set_tn_batch(0)
+        sa, sb = ops.linear_bwd_w_pair(*args)
+    finally:
+        lib.vitmi_debug_set_tn_batch(1)
+    assert torch.equal(sa, ops.linear_bwd_w(args[0], args[1])) and torch.equal(sb, ops.linear_bwd_w(args[2], args[3]))
+    assert rel_err(dwa, sa) < 1e-5 and rel_err(dwb, sb) < 1e-5
+
+
 def test_vit_b16_block_at_batch_128_against_oracle():
     """One ViT-B/16 encoder block (mymodel/ViT.py:93-121 with D 768, H 12, dh 64, mlp 3072) at batch 128, bf16:
     25216 token rows, so qkv / out / fc1 / fc2 and their input gradients have 297-1188 output tiles and run on

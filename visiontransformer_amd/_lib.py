@@ -35,6 +35,9 @@ SIGNATURES = {
     "vitmi_gemm_colsum": (I, [I, I, I, I, P, L, L, P, L, L, P, L, I, I, P, P, L, P, L, P, P, P]),
     "vitmi_gemm_wgrad_workspace_bytes": (L, [I, I, I, I]),
     "vitmi_gemm_wgrad": (I, [I, I, I, I, P, L, P, L, P, L, P, P]),
+    "vitmi_gemm_wgrad_pair_workspace_bytes": (L, [I, I, I, I, I, I]),
+    "vitmi_gemm_wgrad_pair": (I, [I, I, I, I, P, L, P, L, P, I, I, P, L, P, L, P, P, P]),
+    "vitmi_debug_set_tn_batch": (I, [I]),
     "vitmi_transpose_cast": (I, [P, I, P, I, I, P]),
     "vitmi_debug_set_nt_config": (I, [I]),
     "vitmi_debug_set_tn_config": (I, [I]),

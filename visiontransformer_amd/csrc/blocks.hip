@@ -56,8 +56,7 @@ extern "C" int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x,
 
 extern "C" long long vitmi_ff_block_bwd_workspace_bytes(int dt, int rows, int D, int M) {
     if (rows <= 0 || D <= 0 || M <= 0) return 0;
-    long long scratch = vitmi_gemm_wgrad_workspace_bytes(dt, D, M, rows);
-    scratch = max2(scratch, vitmi_gemm_wgrad_workspace_bytes(dt, M, D, rows));
+    long long scratch = vitmi_gemm_wgrad_pair_workspace_bytes(dt, rows, D, M, M, D);
     scratch = max2(scratch, vitmi_gemm_colsum_workspace_bytes(rows, M));
     scratch = max2(scratch, vitmi_layernorm_bwd_workspace_bytes(rows, D));
     return align256((long long)rows * M * esize(dt)) + align256((long long)rows * D * esize(dt)) + align256(scratch);
@@ -76,10 +75,10 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
     void* du = ws;
     void* dxn = ws + align256((long long)rows * M * esize(dt));
     void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
-    STEP(vitmi_gemm_wgrad(dt, D, M, rows, dy, D, h, M, dw2, M, scratch, stream));
     STEP(input_grad(dt, rows, M, D, dy, w2, w2_t, du, g_classic_gelu_pair ? VITMI_EPI_DGELU : VITMI_EPI_MULAUX,
                     const_cast<void*>(u), db1, scratch, stream));
-    STEP(vitmi_gemm_wgrad(dt, M, D, rows, du, M, xn, D, dw1, D, scratch, stream));
+    // both weight gradients of the sub-block share the token axis: one launch where the shapes allow it
+    STEP(vitmi_gemm_wgrad_pair(dt, rows, D, M, dy, D, h, M, dw2, M, D, du, M, xn, D, dw1, scratch, stream));
     STEP(input_grad(dt, rows, D, M, du, w1, w1_t, dxn, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
     STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db2, scratch, dt, rows, D, stream));
     return VITMI_OK;
@@ -105,8 +104,7 @@ extern "C" int vitmi_attn_block_fwd(int dt, int B, int N, int D, int H, int DH, 
 extern "C" long long vitmi_attn_block_bwd_workspace_bytes(int dt, int B, int N, int D, int H, int DH) {
     if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || DH <= 0) return 0;
     const int rows = B * N, I = H * DH;
-    long long scratch = vitmi_gemm_wgrad_workspace_bytes(dt, D, I, rows);
-    scratch = max2(scratch, vitmi_gemm_wgrad_workspace_bytes(dt, 3 * I, D, rows));
+    long long scratch = vitmi_gemm_wgrad_pair_workspace_bytes(dt, rows, D, I, 3 * I, D);
     scratch = max2(scratch, vitmi_attn_bwd_workspace_bytes(dt, B, N, H, DH));
     scratch = max2(scratch, vitmi_colsum_workspace_bytes(rows, 3 * I));
     scratch = max2(scratch, vitmi_layernorm_bwd_workspace_bytes(rows, D));
@@ -130,10 +128,9 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
     void* dqkv = ws + align256((long long)rows * I * esize(dt));
     void* dxn = (char*)dqkv + align256((long long)rows * 3 * I * esize(dt));
     void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
-    STEP(vitmi_gemm_wgrad(dt, D, I, rows, dy, D, o, I, dw_out, I, scratch, stream));
     STEP(input_grad(dt, rows, I, D, dy, w_out, w_out_t, dout, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
     STEP(vitmi_attn_bwd(qkv, o, dout, lse, nullptr, dqkv, scratch, dt, B, N, H, DH, stream));
-    STEP(vitmi_gemm_wgrad(dt, 3 * I, D, rows, dqkv, 3 * I, xn, D, dw_qkv, D, scratch, stream));
+    STEP(vitmi_gemm_wgrad_pair(dt, rows, D, I, dy, D, o, I, dw_out, 3 * I, D, dqkv, 3 * I, xn, D, dw_qkv, scratch, stream));
     if (db_qkv) STEP(vitmi_colsum(dqkv, dt, rows, 3 * I, 3 * I, db_qkv, scratch, stream));
     STEP(input_grad(dt, rows, D, 3 * I, dqkv, w_qkv, w_qkv_t, dxn, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
     STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db_out, scratch, dt, rows, D, stream));

@@ -30,6 +30,9 @@ bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const voi
 int vitmi_gemm_tn_slabs(int P, int Q, int T);
 int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
                        long long ldc, float* slabs, hipStream_t s);
+long long vitmi_gemm_tn_batch_bytes(int n, const int* P, const int* Q, int T);
+int vitmi_gemm_tn_batch(int n, const int* P, const int* Q, int T, const void* const* U, const long long* ldu,
+                        const void* const* V, const long long* ldv, float* const* C, float* partial, hipStream_t s);
 bool vitmi_patch_fast_ok(const void* img, const void* w, const void* out, int W, int p, int D, int E,
                          long long out_batch_stride);
 int vitmi_patch_fwd_fast(const void* img, const void* w, const float* bias, void* out, int B, int C, int H, int W,
@@ -573,4 +576,36 @@ extern "C" int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long
     // general path: the strided GEMM with both operands read along their output index
     return vitmi_gemm(dt, P, Q, T, U, 1, ldu, V, 1, ldv, C, ldc, VITMI_F32, VITMI_EPI_NONE, nullptr, nullptr, 0,
                       nullptr, 0, stream);
+}
+
+extern "C" long long vitmi_gemm_wgrad_pair_workspace_bytes(int dt, int T, int P0, int Q0, int P1, int Q1) {
+    const int P[2] = {P0, P1}, Q[2] = {Q0, Q1};
+    if (dt == VITMI_BF16) {
+        const long long b = vitmi_gemm_tn_batch_bytes(2, P, Q, T);
+        if (b > 0) return b;
+    }
+    const long long w0 = vitmi_gemm_wgrad_workspace_bytes(dt, P0, Q0, T), w1 = vitmi_gemm_wgrad_workspace_bytes(dt, P1, Q1, T);
+    return w0 > w1 ? w0 : w1;
+}
+
+extern "C" int vitmi_gemm_wgrad_pair(int dt, int T, int P0, int Q0, const void* U0, long long ldu0, const void* V0,
+                                     long long ldv0, float* C0, int P1, int Q1, const void* U1, long long ldu1,
+                                     const void* V1, long long ldv1, float* C1, void* workspace, void* stream) {
+    VITMI_CHECK_ARG(U0 && V0 && C0 && U1 && V1 && C1, "vitmi_gemm_wgrad_pair: null operand");
+    VITMI_CHECK_ARG(T > 0 && P0 > 0 && Q0 > 0 && P1 > 0 && Q1 > 0 && ldu0 >= 0 && ldv0 >= 0 && ldu1 >= 0 && ldv1 >= 0,
+                    "vitmi_gemm_wgrad_pair: bad shape");
+    hipStream_t s = as_stream(stream);
+    const int P[2] = {P0, P1}, Q[2] = {Q0, Q1};
+    if (dt == VITMI_BF16 && workspace && vitmi_gemm_tn_batch_bytes(2, P, Q, T) > 0) {
+        const void* U[2] = {U0, U1};
+        const void* V[2] = {V0, V1};
+        const long long ldu[2] = {ldu0, ldu1}, ldv[2] = {ldv0, ldv1};
+        float* C[2] = {C0, C1};
+        ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * ((double)P0 * Q0 + (double)P1 * Q1) * (double)T);
+        const int rc = vitmi_gemm_tn_batch(2, P, Q, T, U, ldu, V, ldv, C, (float*)workspace, s);
+        if (rc != VITMI_ERR_UNSUPPORTED) return rc;
+    }
+    const int rc = vitmi_gemm_wgrad(dt, P0, Q0, T, U0, ldu0, V0, ldv0, C0, Q0, workspace, stream);
+    if (rc != VITMI_OK) return rc;
+    return vitmi_gemm_wgrad(dt, P1, Q1, T, U1, ldu1, V1, ldv1, C1, Q1, workspace, stream);
 }

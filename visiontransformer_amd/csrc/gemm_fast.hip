@@ -929,25 +929,22 @@ __device__ __forceinline__ u32x2 tr_read(unsigned lds_addr) {
     return r;
 }
 
-__global__ __launch_bounds__(512) void gemm_tn_phased_kernel(const bf16_t* __restrict__ U, long long ldu,
-                                                             const bf16_t* __restrict__ V, long long ldv,
-                                                             float* __restrict__ C, long long ldc,
-                                                             long long slab_stride, int P, int Q, int tiles_q,
-                                                             int tiles_pq, int kt_per_slab, int nk_all) {
+// One 256 x 256 tile of C = U^T V over the token tiles [kt_begin, kt_end), all 512 threads of the block:
+// out[p * ldo + q] for p0 <= p < min(p0 + 256, P), q0 <= q < min(q0 + 256, Q).  Leaves every wave behind the
+// same number of barriers with no LDS read outstanding, so a block may call it again (the direct-to-LDS loads of
+// the next call queue behind this call's stores in the in-order vmcnt).
+__device__ __forceinline__ void tn_phased_tile(const bf16_t* __restrict__ U, long long ldu,
+                                               const bf16_t* __restrict__ V, long long ldv, int P, int Q, int p0,
+                                               int q0, int kt_begin, int kt_end, float* __restrict__ out,
+                                               long long ldo, unsigned char* smem_raw) {
     constexpr int RGT = TK * 128;  // elements per region: 64 t x 128 columns
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     typedef __attribute__((address_space(3))) unsigned char* lds_u8p;
     const unsigned lds_base = (unsigned)(size_t)(lds_u8p)smem_raw;
-    const int lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int slab = lin / tiles_pq, tile = lin - slab * tiles_pq;
-    const int p0 = (tile / tiles_q) * 256, q0 = (tile % tiles_q) * 256;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
-    const int kt_begin = slab * kt_per_slab;
-    const int kt_end = min(kt_begin + kt_per_slab, nk_all);
     const int nreg = 4 * max(kt_end - kt_begin, 0);
 
     // a region is 16 loads of 4 token rows; wave w issues loads 2w and 2w+1 of every region
@@ -1107,7 +1104,6 @@ __global__ __launch_bounds__(512) void gemm_tn_phased_kernel(const bf16_t* __res
     if (wr == 0) __builtin_amdgcn_s_barrier();
 
     // acc[j][i][r] = C[p = p0 + wr*128 + i*16 + fr][q = q0 + wc*64 + j*16 + 4*fg + r]
-    float* out = C + (long long)slab * slab_stride;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int pp = p0 + wr * 128 + i * 16 + fr;
@@ -1116,13 +1112,129 @@ __global__ __launch_bounds__(512) void gemm_tn_phased_kernel(const bf16_t* __res
         for (int j = 0; j < 4; ++j) {
             const int qq = q0 + wc * 64 + j * 16 + 4 * fg;
             if (qq + 4 <= Q) {
-                *reinterpret_cast<f32x4*>(out + (long long)pp * ldc + qq) = acc[j][i];
+                *reinterpret_cast<f32x4*>(out + (long long)pp * ldo + qq) = acc[j][i];
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (qq + r < Q) out[(long long)pp * ldc + qq + r] = acc[j][i][r];
+                    if (qq + r < Q) out[(long long)pp * ldo + qq + r] = acc[j][i][r];
             }
         }
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_phased_kernel(const bf16_t* __restrict__ U, long long ldu,
+                                                             const bf16_t* __restrict__ V, long long ldv,
+                                                             float* __restrict__ C, long long ldc,
+                                                             long long slab_stride, int P, int Q, int tiles_q,
+                                                             int tiles_pq, int kt_per_slab, int nk_all) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int slab = lin / tiles_pq, tile = lin - slab * tiles_pq;
+    const int p0 = (tile / tiles_q) * 256, q0 = (tile % tiles_q) * 256;
+    const int kt_begin = slab * kt_per_slab;
+    const int kt_end = min(kt_begin + kt_per_slab, nk_all);
+    tn_phased_tile(U, ldu, V, ldv, P, Q, p0, q0, kt_begin, kt_end, C + (long long)slab * slab_stride, ldc, smem_raw);
+}
+
+// Several weight gradients over the SAME token axis in one launch that fills the chip once (each product alone
+// would pay its own launch, partial-tile write and reduction).  All outputs are multiples of 256 x 256; `tiles`
+// output tiles in all, nk token tiles each.  The first tiles * nmain blocks ("main") own token tiles
+// [slab * a, min((slab + 1) * a, kmain)) of one output tile; the last r = nk - kmain token tiles of ALL output tiles
+// form a tile-major list of tiles * r units that the other blocks take in runs of upl = m * r units, i.e. m whole
+// output tiles one after the other (r = 0: equal slabs only).  Every piece is written as a dense 256 x 256 fp32
+// partial into slot tile * spt + index (main: its slab; run: nmain), which tn_batch_reduce_kernel sums in slot
+// order: deterministic, no atomics.
+struct TnBatchProblem {
+    const bf16_t* U;
+    const bf16_t* V;
+    float* C;
+    long long ldu, ldv, ldc;
+    int Q, tiles_q, tile_begin, pad;
+};
+struct TnBatch {
+    TnBatchProblem pr[4];
+    float* partial;
+    int nprob, tiles, nk, nmain, a, r, upl, spt, main_blocks, kmain;
+};
+constexpr int TN_SLOT = 256 * 256;
+
+__device__ __forceinline__ int tn_batch_problem(const TnBatch& tb, int tile) {
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < tb.nprob && tile >= tb.pr[k].tile_begin) i = k;
+    return i;
+}
+
+__global__ __launch_bounds__(512) void gemm_tn_batch_kernel(const TnBatch tb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // blockIdx & 7 is the XCD.  Every XCD takes an equal share of the runs (they share no operands with their
+    // neighbours, so one XCD holding all of them would be the slowest); its main blocks are consecutive in the
+    // slab-major order, i.e. neighbouring output tiles over the same tokens.
+    const int x = blockIdx.x & 7, l = blockIdx.x >> 3;
+    const int nq = gridDim.x >> 3, nr = gridDim.x & 7;
+    const int runs = gridDim.x - tb.main_blocks, rq = runs >> 3, rr = runs & 7;
+    const int main_x = nq + (x < nr) - rq - (x < rr);
+    const bool is_main = l < main_x;
+    const int run = x * rq + min(x, rr) + (l - main_x);
+    int u = 0, u_end = 0, tile, kb, ke, slot;
+    if (is_main) {
+        const int lin = x * (nq - rq) + min(x, nr) - min(x, rr) + l;
+        const int slab = lin / tb.tiles;
+        tile = lin - slab * tb.tiles;
+        kb = slab * tb.a;
+        ke = min(kb + tb.a, tb.kmain);
+        slot = tile * tb.spt + slab;
+    } else {
+        u = run * tb.upl;
+        u_end = min(u + tb.upl, tb.tiles * tb.r);
+        tile = -1;
+    }
+    for (;;) {
+        if (!is_main) {
+            if (u >= u_end) break;
+            tile = u / tb.r;
+            const int k = u - tile * tb.r;
+            const int len = min(tb.r - k, u_end - u);
+            kb = tb.kmain + k;
+            ke = kb + len;
+            slot = tile * tb.spt + tb.nmain + run - (tile * tb.r) / tb.upl;
+            u += len;
+        }
+        const int i = tn_batch_problem(tb, tile);
+        const TnBatchProblem& pr = tb.pr[i];
+        const int lt = tile - pr.tile_begin;
+        const int p0 = (lt / pr.tiles_q) * 256, q0 = (lt % pr.tiles_q) * 256;
+        float* out = tb.partial + (long long)slot * TN_SLOT - ((long long)p0 * 256 + q0);
+        tn_phased_tile(pr.U, pr.ldu, pr.V, pr.ldv, 1 << 30, 1 << 30, p0, q0, kb, ke, out, 256, smem_raw);
+        if (is_main) break;
+    }
+}
+
+// C tile = sum of its partial slots in slot order; block = (tile, one sixteenth of the tile)
+__global__ __launch_bounds__(256) void tn_batch_reduce_kernel(const TnBatch tb) {
+    const int tile = blockIdx.x >> 4, part = blockIdx.x & 15;
+    int n = tb.nmain;
+    if (tb.r > 0) n += ((tile + 1) * tb.r - 1) / tb.upl - (tile * tb.r) / tb.upl + 1;
+    const int i = tn_batch_problem(tb, tile);
+    const TnBatchProblem& pr = tb.pr[i];
+    const int lt = tile - pr.tile_begin;
+    const int p0 = (lt / pr.tiles_q) * 256, q0 = (lt % pr.tiles_q) * 256;
+    const float* base = tb.partial + (long long)tile * tb.spt * TN_SLOT;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e4 = part * 1024 + it * 256 + threadIdx.x;  // float4 index inside the tile
+        const int row = e4 >> 6, col = (e4 & 63) * 4;
+        f32x4 s = *reinterpret_cast<const f32x4*>(base + 4 * (long long)e4);
+        int k = 1;
+        for (; k + 1 < n; k += 2) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (long long)k * TN_SLOT + 4 * (long long)e4);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (long long)(k + 1) * TN_SLOT + 4 * (long long)e4);
+            s += v0;
+            s += v1;
+        }
+        if (k < n) s += *reinterpret_cast<const f32x4*>(base + (long long)k * TN_SLOT + 4 * (long long)e4);
+        *reinterpret_cast<f32x4*>(pr.C + (long long)(p0 + row) * pr.ldc + q0 + col) = s;
     }
 }
 
@@ -1539,6 +1651,93 @@ int vitmi_gemm_tn_seg_sq(int P, int Q, int T, int seg, const void* U, long long 
 int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
                        long long ldc, float* slabs, hipStream_t s) {
     return launch_tn_fast<false>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, PatchGeom{}, s);
+}
+
+// ---- several weight gradients over one token axis in one launch (gemm_tn_batch_kernel)
+static int g_tn_batch = 1;
+extern "C" int vitmi_debug_set_tn_batch(int on) {
+    g_tn_batch = on;
+    return VITMI_OK;
+}
+
+// geometry of the launch; false when the shapes do not qualify (the caller then runs the products one by one)
+static bool tn_batch_plan(int n, const int* P, const int* Q, int T, TnBatch* tb) {
+    if (!g_tn_batch || n < 2 || n > 4 || T <= 0 || T % TK) return false;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (P[i] <= 0 || Q[i] <= 0 || P[i] % 256 || Q[i] % 256) return false;
+        tb->pr[i].Q = Q[i];
+        tb->pr[i].tiles_q = Q[i] / 256;
+        tb->pr[i].tile_begin = tiles;
+        tb->pr[i].pad = 0;
+        tiles += (P[i] / 256) * (Q[i] / 256);
+    }
+    const int G = phased_grid_blocks(), nk = T / TK;
+    const int nmain = G / tiles;
+    if (nmain < 1 || nk < 4 * (nmain + 1)) return false;
+    const int rem = G - nmain * tiles;
+    int a = ceil_div(nk, nmain), r = 0, upl = 1;
+    // Blocks left over take the last r token tiles of m whole output tiles each, so that all of them walk the same
+    // token tiles at the same time (neighbouring output tiles then share operand panels in L2, as the main blocks
+    // do; runs that start inside an output tile were measured slower than they are shorter).  Worth it when the
+    // left-over blocks are a fair fraction of the chip and r is more than a few token tiles.
+    if (rem * 4 >= tiles) {
+        const int m = ceil_div(tiles, rem);
+        int best = a;
+        const int r0 = nk / (nmain * m + 1);
+        for (int rr = r0 - 1; rr <= r0 + 1; ++rr) {
+            if (rr < 8 || rr >= nk) continue;
+            const int c = ceil_div(nk - rr, nmain);
+            const int worst = c > m * rr ? c : m * rr;
+            if (worst < best) best = worst, a = c, r = rr, upl = m * rr;
+        }
+    }
+    tb->nprob = n;
+    tb->tiles = tiles;
+    tb->nk = nk;
+    tb->nmain = nmain;
+    tb->a = a;
+    tb->r = r;
+    tb->upl = upl;
+    tb->kmain = nk - r;
+    tb->spt = nmain + (r > 0 ? 1 : 0);
+    tb->main_blocks = nmain * tiles;
+    return true;
+}
+
+// bytes of partial tiles the batched launch needs; 0 = these shapes run one by one
+long long vitmi_gemm_tn_batch_bytes(int n, const int* P, const int* Q, int T) {
+    TnBatch tb;
+    if (!tn_batch_plan(n, P, Q, T, &tb)) return 0;
+    return (long long)tb.tiles * tb.spt * TN_SLOT * (long long)sizeof(float);
+}
+
+// C[i] (dense [P[i]][Q[i]] fp32) = U[i]^T V[i] over T tokens for i < n; VITMI_ERR_UNSUPPORTED when the shapes do
+// not qualify
+int vitmi_gemm_tn_batch(int n, const int* P, const int* Q, int T, const void* const* U, const long long* ldu,
+                        const void* const* V, const long long* ldv, float* const* C, float* partial, hipStream_t s) {
+    TnBatch tb;
+    if (!partial || !tn_batch_plan(n, P, Q, T, &tb)) return VITMI_ERR_UNSUPPORTED;
+    for (int i = 0; i < n; ++i) {
+        if (!vitmi_gemm_tn_fast_ok(P[i], Q[i], U[i], ldu[i], V[i], ldv[i], C[i], Q[i])) return VITMI_ERR_UNSUPPORTED;
+        tb.pr[i].U = (const bf16_t*)U[i];
+        tb.pr[i].V = (const bf16_t*)V[i];
+        tb.pr[i].C = C[i];
+        tb.pr[i].ldu = ldu[i];
+        tb.pr[i].ldv = ldv[i];
+        tb.pr[i].ldc = Q[i];
+    }
+    tb.partial = partial;
+    static unsigned long long done = 0;
+    constexpr size_t lds = 2 * 4 * (size_t)TK * 128 * sizeof(bf16_t);
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(gemm_tn_batch_kernel), lds, &done);
+    if (rc != VITMI_OK) return rc;
+    const int runs = tb.r > 0 ? ceil_div(tb.tiles * tb.r, tb.upl) : 0;
+    hipLaunchKernelGGL(gemm_tn_batch_kernel, dim3(tb.main_blocks + runs), dim3(512), lds, s, tb);
+    VITMI_LAUNCH_CHECK("vitmi_gemm_wgrad_batch(tn phased)");
+    hipLaunchKernelGGL(tn_batch_reduce_kernel, dim3(tb.tiles * 16), dim3(256), 0, s, tb);
+    VITMI_LAUNCH_CHECK("vitmi_gemm_wgrad_batch(reduce)");
+    return VITMI_OK;
 }
 
 // patch-embedding weight gradient on a bf16 image: dW[d][e] = sum_t dy[t][d] * P[t][e]

@@ -246,6 +246,22 @@ def linear_bwd_w(dy2, x2):
     return dw
 
 
+def linear_bwd_w_pair(dy_a, x_a, dy_b, x_b):
+    """The two weight gradients of a sub-block, dy_a^T @ x_a and dy_b^T @ x_b over the same tokens, through
+    vitmi_gemm_wgrad_pair (one launch for bf16 operands whose extents are multiples of 256)."""
+    T, Na = dy_a.shape
+    Ka, Nb, Kb = x_a.shape[1], dy_b.shape[1], x_b.shape[1]
+    assert dy_b.shape[0] == T and x_a.shape[0] == T and x_b.shape[0] == T
+    dwa = torch.empty((Na, Ka), dtype=torch.float32, device=dy_a.device)
+    dwb = torch.empty((Nb, Kb), dtype=torch.float32, device=dy_a.device)
+    dt = _dt(dy_a)
+    ws = _ws(lib.vitmi_gemm_wgrad_pair_workspace_bytes(dt, T, Na, Ka, Nb, Kb), dy_a.device)
+    check(lib.vitmi_gemm_wgrad_pair(dt, T, Na, Ka, _p(dy_a), dy_a.stride(0), _p(x_a), x_a.stride(0), _p(dwa),
+                                    Nb, Kb, _p(dy_b), dy_b.stride(0), _p(x_b), x_b.stride(0), _p(dwb), _p(ws),
+                                    _stream()), "vitmi_gemm_wgrad_pair")
+    return dwa, dwb
+
+
 def weight_t(param, cdt):
     """Transposed bf16 copy for the input-gradient product, or None in fp32 mode."""
     return compute_copy_t(param, cdt) if cdt == torch.bfloat16 else None
