@@ -99,7 +99,7 @@ def cpu_baseline(kw, masked, seconds_budget=14.0):
             "cpu_model": cpu_model_name(), "host_cpus": os.cpu_count()}
 
 
-PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02d_pmc_traffic.json")
 # timer family -> substrings of the names, in the rocprofv3 counter summary, of the kernels one call of the family
 # launches: the first is the main kernel; a GEMM call also launches the small-tile kernel on the rows of a thin last
 # round (nt) or the slab reduction (tn)
