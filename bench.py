@@ -106,7 +106,7 @@ PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pro
 PMC_KERNELS_OF_FAMILY = {
     "gemm_nt_phased_kernel|gemm_nt_fast_kernel[plain->bf16]": ["gemm_nt_phased_kernelILi0EDF16b",
                                                                "gemm_nt_fast_kernelILi0EDF16bLb0ELi128ELi128"],
-    "gemm_tn_phased_kernel|gemm_tn_fast_kernel[+slab_reduce]": ["gemm_tn_phased_kernel", "slab_reduce_kernel"],
+    "gemm_tn_batch_kernel|gemm_tn_phased_kernel|gemm_tn_fast_kernel[+reduce]": ["gemm_tn_batch_kernel", "tn_batch_reduce_kernel"],
 }
 
 

@@ -153,6 +153,6 @@ extern "C" const char* vitmi_prof_name(int family) {
         snprintf(buf, sizeof(buf), "gemm_nt_phased_kernel|gemm_nt_fast_kernel[%s]", epi[family - VITMI_FAM_GEMM_NT_FAST0]);
         return buf;
     }
-    if (family == VITMI_FAM_GEMM_TN_FAST) return "gemm_tn_phased_kernel|gemm_tn_fast_kernel[+slab_reduce]";
+    if (family == VITMI_FAM_GEMM_TN_FAST) return "gemm_tn_batch_kernel|gemm_tn_phased_kernel|gemm_tn_fast_kernel[+reduce]";
     return "?";
 }
