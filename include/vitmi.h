@@ -43,6 +43,10 @@ extern "C" {
  * derivative lies in [-0.13, 1.13] and half keeps 11 significant bits of it. */
 #define VITMI_EPI_GELU_D 3 /* pre = acc + bias[n]; aux(m,n) = gelu_erf'(pre) (if aux); C = gelu_erf(pre)  */
 #define VITMI_EPI_MULAUX 4 /* C = acc * aux(m,n)                                                           */
+/* LayerNorm folded into the product (vitmi_gemm_ln only): A holds the raw rows x, B the weight times gamma;
+ * C = rstd[m] * (acc - mean[m] * s[n]) + bias[n], s[n] = sum_k B[n][k], bias = W beta + b; _GELU: gelu_erf of that */
+#define VITMI_EPI_LN 5
+#define VITMI_EPI_LN_GELU 6
 
 /* kernel families for the launch timers (vitmi_prof_*) */
 #define VITMI_FAM_GEMM 0
@@ -343,6 +347,29 @@ int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, const void*
                          const float* rstd, const void* w_qkv, const void* w_qkv_t, const void* w_out,
                          const void* w_out_t, void* dx, float* dgamma, float* dbeta, float* dw_qkv, float* db_qkv,
                          float* dw_out, float* db_out, void* workspace, void* stream);
+
+/* The same two sub-blocks for inference (no autograd graph: model.eval() under torch.no_grad(), the mode of
+ * mia_attn.py / vit_rollout.py / every evaluation loop of trainer.py), bf16 only, nothing kept for a backward pass.
+ * nn.LayerNorm + nn.Linear (mymodel/ViT.py:55,58 in front of :86 and :66) run as ONE product: the normalised rows are
+ * never written.  vitmi_row_stats leaves mean and 1/sqrt(var + eps) per row; vitmi_gemm_ln multiplies the RAW rows by
+ * the weight with gamma folded in and finishes in its epilogue,
+ *     y[m][n] = rstd[m] * (sum_k x[m][k] Wg[n][k] - mean[m] * s[n]) + c[n],
+ *     Wg = bf16(W * gamma) [N,K],  s[n] = sum_k Wg[n][k] (fp32, of the rounded values),  c = W beta + b (fp32),
+ * VITMI_EPI_LN_GELU applying gelu_erf to that (the MLP's first layer; no derivative is stored).  The folded
+ * operands are made once per weight version by the caller.  probs and b_out may be NULL. */
+int vitmi_row_stats(const void* x, long long ldx, float* mean, float* rstd, int dt, long long rows, int D, float eps,
+                    void* stream);
+int vitmi_gemm_ln(int M, int N, int K, const void* x, long long ldx, const void* w_folded, const float* bias_folded,
+                  const float* w_rowsum, const float* mean, const float* rstd, void* C, long long ldc, int epilogue,
+                  void* stream);
+long long vitmi_attn_block_infer_workspace_bytes(int B, int N, int D, int H, int DH);
+int vitmi_attn_block_infer(int B, int N, int D, int H, int DH, const void* x, float eps, const void* wq_folded,
+                           const float* bq_folded, const float* wq_rowsum, const void* w_out, const float* b_out,
+                           void* probs, void* y, void* workspace, void* stream);
+long long vitmi_ff_block_infer_workspace_bytes(int rows, int D, int M);
+int vitmi_ff_block_infer(int rows, int D, int M, const void* x, float eps, const void* w1_folded,
+                         const float* b1_folded, const float* w1_rowsum, const void* w2, const float* b2, void* y,
+                         void* workspace, void* stream);
 
 /* Per-sample gradient norms for DP-SGD (defence_method/DPSGD.py:114-136, which clips each sample's gradient and
  * gets per-sample gradients by running the batch one image at a time).  Rows of the [tokens, features]

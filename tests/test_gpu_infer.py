@@ -1,0 +1,126 @@
+"""GPU parity tests of the inference entry points: LayerNorm folded into the product behind it (vitmi_row_stats +
+vitmi_gemm_ln, VITMI_EPI_LN / VITMI_EPI_LN_GELU), the two sub-blocks without saved tensors, and whole models run
+under torch.no_grad() against the fixtures captured from the reference.  bf16 bar 2e-2 relative."""
+import ctypes
+
+import pytest
+import torch
+
+from conftest import Golden, VIT_CASES, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def q(t):
+    return t.to(BF).float()
+
+
+@pytest.mark.parametrize("M,N,K", [
+    (50432, 2304, 768),     # qkv of ViT-B/16 at batch 256: gemm_nt_phased_kernel<LN>
+    (50432 - 100, 3072, 768),   # fc1 with a ragged last row tile: <LN_GELU>
+    (16640, 576, 192),      # the 32 x 32 geometry at batch 256 (65 tokens): 128 x 128 tiles
+    (1000, 200, 264),       # ragged in every extent: generic epilogue rows
+    (197, 768, 768),
+])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_layernorm_folded_product(M, N, K, gelu):
+    from visiontransformer_amd import ops
+    from visiontransformer_amd._lib import check, lib
+    # rows with a mean that is not small against their deviation, as a residual stream has
+    x = (rnd(M, K, seed=1, scale=2.0) + rnd(M, 1, seed=2, scale=3.0) + 1.5).to(BF)
+    w, b = rnd(N, K, seed=3, scale=K ** -0.5), rnd(N, seed=4, scale=0.1)
+    gamma, beta = 1.0 + 0.2 * rnd(K, seed=5), 0.1 * rnd(K, seed=6)
+    xd = x.to(DEV)
+    wp, bp, gp, btp = (torch.nn.Parameter(t.to(DEV)) for t in (w, b, gamma, beta))
+    wg, s, c = ops.folded_linear(wp, gp, btp, bp)
+    assert ops.folded_linear(wp, gp, btp, bp)[0] is wg                       # cached
+    mean = torch.empty(M, device=DEV)
+    rstd = torch.empty(M, device=DEV)
+    y = torch.empty(M, N, dtype=BF, device=DEV)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib.vitmi_row_stats(xd.data_ptr(), K, mean.data_ptr(), rstd.data_ptr(), 1, M, K, 1e-5, st), "vitmi_row_stats")
+    check(lib.vitmi_gemm_ln(M, N, K, xd.data_ptr(), K, wg.data_ptr(), c.data_ptr(), s.data_ptr(), mean.data_ptr(),
+                            rstd.data_ptr(), y.data_ptr(), N, 6 if gelu else 5, st), "vitmi_gemm_ln")
+    xf = x.double()
+    mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+    assert rel_err(mean, mu[:, 0]) < 1e-5 and rel_err(rstd, (var[:, 0] + 1e-5).rsqrt()) < 1e-5
+    ref = ((xf - mu) / (var + 1e-5).sqrt() * gamma.double() + beta.double()) @ w.double().t() + b.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    assert rel_err(y, ref) < 1e-2
+    with torch.no_grad():
+        gp.mul_(1.5)                                                         # a new version of one of the four
+    assert ops.folded_linear(wp, gp, btp, bp)[0] is not wg
+
+
+def build(g, grad):
+    import visiontransformer_amd
+    m = getattr(visiontransformer_amd, g.module).VIT(**g.ctor_kwargs())
+    m.load_state_dict(g.params, strict=True)
+    m = m.to(DEV).set_compute_dtype(BF)
+    if g.masked:
+        m.train_method = "mask"
+    return m.eval()
+
+
+def run(m, g):
+    if g.module != "ViT":
+        return m(g.x.to(DEV), unk_mask=g.unk_mask.to(DEV) if g.unk_mask is not None else None)
+    return m(g.x.to(DEV))
+
+
+@pytest.mark.parametrize("case", VIT_CASES)
+def test_no_grad_forward_against_reference_fixture(case):
+    """model.eval() under torch.no_grad() takes vitmi_attn_block_infer / vitmi_ff_block_infer; the logits meet the
+    reference's at the bf16 bar, and so does the same call with the inference entry points switched off."""
+    from visiontransformer_amd import ops
+    g = Golden(case)
+    m = build(g, False)
+    with torch.no_grad():
+        fused = run(m, g)
+        prev = ops.set_inference_fusion(False)
+        try:
+            plain = run(m, g)
+        finally:
+            ops.set_inference_fusion(prev)
+    assert rel_err(fused, g.logits) < 2e-2 and rel_err(plain, g.logits) < 2e-2
+    assert rel_err(fused, plain) < 2e-2 and not torch.equal(fused, plain)      # two different routes
+    again = None
+    with torch.no_grad():
+        again = run(m, g)
+    assert torch.equal(fused, again)
+
+
+@pytest.mark.parametrize("case", ["cifar_dh8", "n197_dh64"])
+def test_no_grad_probability_export(case):
+    """The probabilities a forward hook on attn_drop sees under torch.no_grad() (vit_rollout.py:85-98, mia_attn.py)
+    against the reference's."""
+    g = Golden(case)
+    m = build(g, False)
+    seen = []
+    hooks = [mod.register_forward_hook(lambda _m, _i, out: seen.append(out)) for name, mod in m.named_modules()
+             if name.endswith("attn_drop")]
+    with torch.no_grad():
+        run(m, g)
+    for h in hooks:
+        h.remove()
+    assert len(seen) == len(g.probs) and len(seen) > 0
+    for i, got in enumerate(seen):
+        assert rel_err(got, g.probs[i]) < 2e-2
+
+
+def test_inference_blocks_leave_training_alone():
+    """With a parameter that requires grad and grad mode on, the same modules build their autograd graph (training
+    entry points) -- the inference path is taken only when no input needs a gradient."""
+    g = Golden("cifar_dh8")
+    m = build(g, True)
+    out = run(m, g)
+    assert out.requires_grad
+    out.float().sum().backward()
+    assert all(p.grad is not None for n, p in m.named_parameters() if "unk" not in n and "mask" not in n)

@@ -38,6 +38,12 @@ SIGNATURES = {
     "vitmi_gemm_wgrad_pair_workspace_bytes": (L, [I, I, I, I, I, I]),
     "vitmi_gemm_wgrad_pair": (I, [I, I, I, I, P, L, P, L, P, I, I, P, L, P, L, P, P, P]),
     "vitmi_debug_set_tn_batch": (I, [I]),
+    "vitmi_row_stats": (I, [P, L, P, P, I, L, I, F, P]),
+    "vitmi_gemm_ln": (I, [I, I, I, P, L, P, P, P, P, P, P, L, I, P]),
+    "vitmi_attn_block_infer_workspace_bytes": (L, [I, I, I, I, I]),
+    "vitmi_attn_block_infer": (I, [I, I, I, I, I, P, F, P, P, P, P, P, P, P, P, P]),
+    "vitmi_ff_block_infer_workspace_bytes": (L, [I, I, I]),
+    "vitmi_ff_block_infer": (I, [I, I, I, P, F, P, P, P, P, P, P, P, P]),
     "vitmi_transpose_cast": (I, [P, I, P, I, I, P]),
     "vitmi_debug_set_nt_config": (I, [I]),
     "vitmi_debug_set_tn_config": (I, [I]),

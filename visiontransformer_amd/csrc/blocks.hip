@@ -136,3 +136,56 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
     STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db_out, scratch, dt, rows, D, stream));
     return VITMI_OK;
 }
+
+// ------------------------------------------------------------------------------- inference (nothing kept for a backward)
+// bf16 only.  LayerNorm never writes its normalised rows: a statistics pass over x, then the product on the raw rows
+// with gamma folded into the weight and mean / rstd applied in the epilogue (VITMI_EPI_LN); the MLP's first product
+// applies GELU in the same epilogue and stores no derivative.
+static long long infer_stats_bytes(long long rows) { return 2 * align256(rows * (long long)sizeof(float)); }
+
+extern "C" long long vitmi_attn_block_infer_workspace_bytes(int B, int N, int D, int H, int DH) {
+    if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || DH <= 0) return 0;
+    const long long rows = (long long)B * N, I = (long long)H * DH;
+    return infer_stats_bytes(rows) + align256(rows * 3 * I * 2) + align256(rows * I * 2) +
+           align256((long long)B * H * N * (long long)sizeof(float));
+}
+
+extern "C" int vitmi_attn_block_infer(int B, int N, int D, int H, int DH, const void* x, float eps, const void* wq_folded,
+                                      const float* bq_folded, const float* wq_rowsum, const void* w_out,
+                                      const float* b_out, void* probs, void* y, void* workspace, void* stream) {
+    VITMI_CHECK_ARG(x && wq_folded && bq_folded && wq_rowsum && w_out && y && workspace, "vitmi_attn_block_infer: null pointer");
+    VITMI_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && DH > 0, "vitmi_attn_block_infer: bad shape");
+    const int rows = B * N, I = H * DH;
+    char* ws = (char*)workspace;
+    float* mean = (float*)ws;
+    float* rstd = (float*)(ws + align256((long long)rows * sizeof(float)));
+    void* qkv = ws + infer_stats_bytes(rows);
+    void* o = (char*)qkv + align256((long long)rows * 3 * I * 2);
+    float* lse = (float*)((char*)o + align256((long long)rows * I * 2));
+    STEP(vitmi_row_stats(x, D, mean, rstd, VITMI_BF16, rows, D, eps, stream));
+    STEP(vitmi_gemm_ln(rows, 3 * I, D, x, D, wq_folded, bq_folded, wq_rowsum, mean, rstd, qkv, 3 * I, VITMI_EPI_LN, stream));
+    STEP(vitmi_attn_fwd(qkv, o, lse, probs, VITMI_BF16, B, N, H, DH, stream));
+    STEP(vitmi_gemm(VITMI_BF16, rows, D, I, o, I, 1, w_out, I, 1, y, D, VITMI_BF16, VITMI_EPI_NONE, b_out, x, D, nullptr, 0,
+                    stream));
+    return VITMI_OK;
+}
+
+extern "C" long long vitmi_ff_block_infer_workspace_bytes(int rows, int D, int M) {
+    if (rows <= 0 || D <= 0 || M <= 0) return 0;
+    return infer_stats_bytes(rows) + align256((long long)rows * M * 2);
+}
+
+extern "C" int vitmi_ff_block_infer(int rows, int D, int M, const void* x, float eps, const void* w1_folded,
+                                    const float* b1_folded, const float* w1_rowsum, const void* w2, const float* b2,
+                                    void* y, void* workspace, void* stream) {
+    VITMI_CHECK_ARG(x && w1_folded && b1_folded && w1_rowsum && w2 && y && workspace, "vitmi_ff_block_infer: null pointer");
+    VITMI_CHECK_ARG(rows > 0 && D > 0 && M > 0, "vitmi_ff_block_infer: bad shape rows=%d D=%d M=%d", rows, D, M);
+    char* ws = (char*)workspace;
+    float* mean = (float*)ws;
+    float* rstd = (float*)(ws + align256((long long)rows * sizeof(float)));
+    void* h = ws + infer_stats_bytes(rows);
+    STEP(vitmi_row_stats(x, D, mean, rstd, VITMI_BF16, rows, D, eps, stream));
+    STEP(vitmi_gemm_ln(rows, M, D, x, D, w1_folded, b1_folded, w1_rowsum, mean, rstd, h, M, VITMI_EPI_LN_GELU, stream));
+    STEP(vitmi_gemm(VITMI_BF16, rows, D, M, h, M, 1, w2, M, 1, y, D, VITMI_BF16, VITMI_EPI_NONE, b2, x, D, nullptr, 0, stream));
+    return VITMI_OK;
+}

@@ -58,7 +58,8 @@ __device__ __forceinline__ float deriv_pack(float v, float) { return v; }
 __device__ __forceinline__ float deriv_unpack(__bf16 b) { return (float)__builtin_bit_cast(_Float16, b); }
 __device__ __forceinline__ float deriv_unpack(float v) { return v; }
 
-constexpr bool epi_is_gelu(int epi) { return epi == VITMI_EPI_GELU || epi == VITMI_EPI_GELU_D; }
+constexpr bool epi_is_gelu(int epi) { return epi == VITMI_EPI_GELU || epi == VITMI_EPI_GELU_D || epi == VITMI_EPI_LN_GELU; }
+constexpr bool epi_is_ln(int epi) { return epi == VITMI_EPI_LN || epi == VITMI_EPI_LN_GELU; }
 constexpr bool epi_is_auxmul(int epi) { return epi == VITMI_EPI_DGELU || epi == VITMI_EPI_MULAUX; }
 
 // ---- dtype traits --------------------------------------------------------------------------

@@ -963,6 +963,93 @@ extern "C" int vitmi_layernorm_fwd(const void* x, long long ldx, const float* ga
     return VITMI_OK;
 }
 
+// mean and 1/sqrt(var + eps) of every row, nothing else: what a product with LayerNorm folded into its weight
+// needs of the rows (VITMI_EPI_LN).  Same row walk as layernorm_fwd_kernel, one row ahead.
+template <typename T, int V, int ITERS>
+__global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x, long long ldx, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, long long rows, int D, float eps) {
+    typedef Vec<T, V> __attribute__((aligned(sizeof(T) * V))) VT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const long long stride = (long long)gridDim.x * nw;
+    VT nx[ITERS];
+    auto fetch = [&](long long row) {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
+            if (c < D) nx[it] = *reinterpret_cast<const VT*>(x + row * ldx + c);
+        }
+    };
+    long long row = (long long)blockIdx.x * nw + wave;
+    if (row < rows) fetch(row);
+    for (; row < rows; row += stride) {
+        float v[ITERS][V];
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                v[it][j] = c < D ? to_f32(nx[it].v[j]) : 0.f;
+                sum += v[it][j];
+            }
+        }
+        if (row + stride < rows) fetch(row + stride);
+        const float mu = wave_sum(sum) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = (it * 64 + lane) * V;
+            if (c < D) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float d = v[it][j] - mu;
+                    q += d * d;
+                }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+extern "C" int vitmi_row_stats(const void* x, long long ldx, float* mean, float* rstd, int dt, long long rows, int D,
+                               float eps, void* stream) {
+    VITMI_CHECK_ARG(x && mean && rstd, "vitmi_row_stats: null pointer");
+    VITMI_CHECK_ARG(rows > 0 && D > 0 && ldx >= D, "vitmi_row_stats: bad shape rows=%lld D=%d ldx=%lld", rows, D, ldx);
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_row_stats: bad dtype %d", dt);
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_LAYERNORM, s, 1.0 * rows * D * (dt == VITMI_F32 ? 4 : 2));
+    const bool vec = (D % 4 == 0) && (ldx % 4 == 0) && aligned_to(x, 16);
+    const int iters = ceil_div(D, 64 * (vec ? 4 : 1));
+    if (iters > 8) {
+        vitmi_set_error("vitmi_row_stats: D=%d exceeds the supported row length %d", D, 64 * 8 * (vec ? 4 : 1));
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    dim3 grid((unsigned)std::min<long long>(ceil_div(rows, 4), 1024)), block(256);
+#define RS(T, V, I) hipLaunchKernelGGL((row_stats_kernel<T, V, I>), grid, block, 0, s, (const T*)x, ldx, mean, rstd, rows, D, eps)
+#define RS_I(T, V)                         \
+    do {                                   \
+        if (iters <= 1) RS(T, V, 1);       \
+        else if (iters == 2) RS(T, V, 2);  \
+        else if (iters == 3) RS(T, V, 3);  \
+        else if (iters == 4) RS(T, V, 4);  \
+        else if (iters <= 6) RS(T, V, 6);  \
+        else RS(T, V, 8);                  \
+    } while (0)
+    if (dt == VITMI_F32) {
+        if (vec) RS_I(float, 4); else RS_I(float, 1);
+    } else {
+        if (vec) RS_I(bf16_t, 4); else RS_I(bf16_t, 1);
+    }
+#undef RS_I
+#undef RS
+    VITMI_LAUNCH_CHECK("vitmi_row_stats");
+    return VITMI_OK;
+}
+
 extern "C" long long vitmi_layernorm_bwd_workspace_bytes(long long rows, int D) {
     return (long long)ln_bwd_blocks(rows) * 3 * D * (long long)sizeof(float);
 }

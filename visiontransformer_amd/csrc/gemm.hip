@@ -21,6 +21,9 @@ bool vitmi_gemm_nt_fast_ok(int M, int N, int K, const void* A, long long lda, co
 int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
                        long long ldc, int c_dt, int epilogue, const float* bias, const void* residual, long long ldr,
                        void* aux, long long ldaux, float* cs_partial, hipStream_t s);
+int vitmi_gemm_nt_fast_ln(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
+                          long long ldc, int epilogue, const float* bias, const float* ln_mean, const float* ln_rstd,
+                          const float* ln_s, hipStream_t s);
 bool vitmi_gemm_nt_phased_ok(int M, int N, int K);
 int vitmi_gemm_nt_colsum_rows(int M);
 int vitmi_colsum_final_launch(const float* partial, int chunks, int cols, float* out, hipStream_t s);
@@ -437,6 +440,22 @@ extern "C" int vitmi_gemm(int dt, int M, int N, int K, const void* A, long long 
                           void* stream) {
     return gemm_impl(dt, M, N, K, A, sam, sak, B, sbn, sbk, C, ldc, c_dt, epilogue, bias, residual, ldr, aux, ldaux,
                      nullptr, stream);
+}
+
+extern "C" int vitmi_gemm_ln(int M, int N, int K, const void* x, long long ldx, const void* w_folded,
+                             const float* bias_folded, const float* w_rowsum, const float* mean, const float* rstd,
+                             void* C, long long ldc, int epilogue, void* stream) {
+    VITMI_CHECK_ARG(x && w_folded && bias_folded && w_rowsum && mean && rstd && C, "vitmi_gemm_ln: null pointer");
+    VITMI_CHECK_ARG(M > 0 && N > 0 && K > 0 && ldx >= K && ldc >= N, "vitmi_gemm_ln: bad shape M=%d N=%d K=%d", M, N, K);
+    VITMI_CHECK_ARG(epilogue == VITMI_EPI_LN || epilogue == VITMI_EPI_LN_GELU, "vitmi_gemm_ln: bad epilogue %d", epilogue);
+    if (!vitmi_gemm_nt_fast_ok(M, N, K, x, ldx, w_folded, K, C, ldc, VITMI_BF16, nullptr, 0, nullptr, 0) ||
+        ((size_t)bias_folded | (size_t)w_rowsum) % 16 || N % 8) {
+        vitmi_set_error("vitmi_gemm_ln: operands must be 16-byte aligned with K, N, ldx, ldc multiples of 8");
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_GEMM_NT_FAST0 + (epilogue == VITMI_EPI_LN ? 0 : 1), s, 2.0 * M * N * K);
+    return vitmi_gemm_nt_fast_ln(M, N, K, x, ldx, w_folded, K, C, ldc, epilogue, bias_folded, mean, rstd, w_rowsum, s);
 }
 
 extern "C" long long vitmi_gemm_colsum_workspace_bytes(int M, int N) {

@@ -103,6 +103,11 @@ struct FastEpi {
     int rows_per_group;      // > 0: row m lives at C + (m / rpg) * group_stride + (m % rpg) * ldc
     long long group_stride;
     float* cs_partial;       // phased kernel only: [2 * m-tiles][N] column sums of the stored values
+    // VITMI_EPI_LN / VITMI_EPI_LN_GELU: A holds the raw rows x and B the weight with LayerNorm's gamma folded in;
+    // acc becomes rstd[m] * (acc - mean[m] * ln_s[n]) (ln_s[n] = row sum of the folded weight) before the bias
+    const float* ln_mean;
+    const float* ln_rstd;
+    const float* ln_s;
 };
 
 // v[t] belongs to row m, column n + (t & 7) + (t >> 3) * H2: two runs of 8 consecutive columns, H2
@@ -111,6 +116,11 @@ template <int EPI, typename OutT, int H2 = 8>
 __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N, float (&v)[16]) {
     const bool full = (n + H2 + 8 <= N);
     auto col = [&](int t) { return n + (t & 7) + (t >> 3) * H2; };
+    if (epi_is_ln(EPI)) {
+        const float mu = e.ln_mean[m], rs = e.ln_rstd[m];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = rs * (v[t] - mu * (col(t) < N ? e.ln_s[col(t)] : 0.f));
+    }
     if (e.bias) {
         if (full) {
 #pragma unroll
@@ -238,6 +248,20 @@ __device__ __forceinline__ void epi_subtile_fast(const FastEpi& e, f32x4 (&acc)[
 #pragma unroll
         for (int t = 0; t < 4; ++t) b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    f32x4 ls[4];
+    float lmu[8], lrs[8];
+    if (epi_is_ln(EPI)) {
+        ls[0] = *reinterpret_cast<const f32x4*>(e.ln_s + n);
+        ls[1] = *reinterpret_cast<const f32x4*>(e.ln_s + n + 4);
+        ls[2] = *reinterpret_cast<const f32x4*>(e.ln_s + n + 32);
+        ls[3] = *reinterpret_cast<const f32x4*>(e.ln_s + n + 36);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = min(mrow0 + 16 * i, M - 1);
+            lmu[i] = e.ln_mean[m];
+            lrs[i] = e.ln_rstd[m];
+        }
+    }
     const bf16_t* op = epi_is_auxmul(EPI) ? e.aux : e.res;
     const long long ldop = epi_is_auxmul(EPI) ? e.ldaux : e.ldr;
     bf16x8 o[8][2];
@@ -260,7 +284,8 @@ __device__ __forceinline__ void epi_subtile_fast(const FastEpi& e, f32x4 (&acc)[
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[j][i][r] + b[j][r];
+            for (int r = 0; r < 4; ++r)
+                v[4 * j + r] = epi_is_ln(EPI) ? fmaf(lrs[i], acc[j][i][r] - lmu[i] * ls[j][r], b[j][r]) : acc[j][i][r] + b[j][r];
         if (epi_is_gelu(EPI)) {
             bf16x8 p0, p1;
 #pragma unroll
@@ -1454,6 +1479,7 @@ static int launch_nt_epi(int M, int N, int K, const bf16_t* a, long long lda, co
                     t.C = reinterpret_cast<OutT*>(e.C) + (long long)M1 * e.ldc;
                     if (e.res) t.res = e.res + (long long)M1 * e.ldr;
                     if (e.aux) t.aux = e.aux + (long long)M1 * e.ldaux;
+                    if (e.ln_mean) t.ln_mean = e.ln_mean + M1, t.ln_rstd = e.ln_rstd + M1;
                     return launch_nt_cfg<EPI, OutT, PATCH, 128, 128, 2, 2>(M - M1, N, K, a + (long long)M1 * lda, lda, b, ldb,
                                                                          t, pg, s);
                 }
@@ -1484,6 +1510,10 @@ static int launch_nt_fast(int M, int N, int K, const void* A, long long lda, con
             return launch_nt_epi<VITMI_EPI_GELU_D, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
         if (epilogue == VITMI_EPI_MULAUX)
             return launch_nt_epi<VITMI_EPI_MULAUX, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+        if (epilogue == VITMI_EPI_LN)
+            return launch_nt_epi<VITMI_EPI_LN, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
+        if (epilogue == VITMI_EPI_LN_GELU)
+            return launch_nt_epi<VITMI_EPI_LN_GELU, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
         return launch_nt_epi<VITMI_EPI_DGELU, bf16_t, PATCH>(M, N, K, a, lda, b, ldb, e, pg, s);
     }
 }
@@ -1496,8 +1526,17 @@ int vitmi_gemm_nt_colsum_rows(int M) { return 2 * ceil_div(M, 256); }
 int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
                        long long ldc, int c_dt, int epilogue, const float* bias, const void* residual, long long ldr,
                        void* aux, long long ldaux, float* cs_partial, hipStream_t s) {
-    FastEpi e{C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)aux, ldaux, 0, 0, cs_partial};
+    FastEpi e{C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)aux, ldaux, 0, 0, cs_partial, nullptr, nullptr, nullptr};
     return launch_nt_fast<false>(M, N, K, A, lda, B, ldb, e, c_dt, epilogue, PatchGeom{}, s);
+}
+
+// C (bf16) = epilogue(LayerNorm(x) W^T + b) without the normalised rows ever being formed: A = x, B = the weight
+// with gamma folded in, epilogue VITMI_EPI_LN or VITMI_EPI_LN_GELU, bias = W beta + b, ln_s = row sums of B
+int vitmi_gemm_nt_fast_ln(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
+                          long long ldc, int epilogue, const float* bias, const float* ln_mean, const float* ln_rstd,
+                          const float* ln_s, hipStream_t s) {
+    FastEpi e{C, ldc, bias, nullptr, 0, nullptr, 0, 0, 0, nullptr, ln_mean, ln_rstd, ln_s};
+    return launch_nt_fast<false>(M, N, K, A, lda, B, ldb, e, VITMI_BF16, epilogue, PatchGeom{}, s);
 }
 
 // patch-embedding forward on a bf16 image: tokens x D = patches x W^T, rows land at
@@ -1512,7 +1551,7 @@ int vitmi_patch_fwd_fast(const void* img, const void* w, const float* bias, void
                          int p, int D, long long out_batch_stride, hipStream_t s) {
     const int gh = H / p, gw = W / p, per = gh * gw, E = C * p * p;
     PatchGeom pg{C, H, W, p, gw, per, B * per, E};
-    FastEpi e{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride, nullptr};
+    FastEpi e{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride, nullptr, nullptr, nullptr, nullptr};
     return launch_nt_fast<true>(B * per, D, E, img, 0, w, E, e, VITMI_BF16, VITMI_EPI_NONE, pg, s);
 }
 

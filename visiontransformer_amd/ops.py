@@ -4,6 +4,7 @@ Every function here moves raw device pointers, shapes and the current HIP stream
 boundary; tensors are allocated by PyTorch's caching allocator.  There is no CPU or eager
 fallback: CPU tensors raise.
 """
+import os
 import weakref
 
 import torch
@@ -151,6 +152,43 @@ def compute_copy_t(param, dtype):
     return out
 
 
+# LayerNorm folded into the weight of the Linear behind it, for the inference entry points (vitmi_gemm_ln):
+# (Wg, s, c) = (bf16(W * gamma), row sums of Wg in fp32, W beta + b in fp32), cached until one of the four
+# parameters changes.  Weight preparation, like the compute copies above; a few launches per weight version.
+_fold_cache = {}
+_infer_fusion = os.environ.get("VITMI_INFER_FUSION", "1") != "0"
+
+
+def set_inference_fusion(on):
+    """Whether forward passes that build no autograd graph take the LayerNorm-folded inference entry points
+    (default on; VITMI_INFER_FUSION=0 turns it off at import).  Returns the previous setting."""
+    global _infer_fusion
+    prev, _infer_fusion = _infer_fusion, bool(on)
+    return prev
+
+
+def folded_linear(w, ln_w, ln_b, b):
+    parts = [t for t in (w, ln_w, ln_b, b) if t is not None]
+    key = tuple(id(t) for t in (w, ln_w, ln_b, b))
+    stamp = tuple((t._version, t.data_ptr()) for t in parts)
+    hit = _fold_cache.get(key)
+    if hit is not None and hit[0] == stamp and all(r() is t for r, t in zip(hit[1], parts)):
+        return hit[2]
+    with torch.no_grad():
+        w32 = w.detach().float()
+        wg = (w32 * ln_w.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+        s = wg.float().sum(dim=1).contiguous()
+        c = w32 @ ln_b.detach().float()
+        if b is not None:
+            c = c + b.detach().float()
+        c = c.contiguous()
+
+    def _drop(_ref, key=key):
+        _fold_cache.pop(key, None)
+    _fold_cache[key] = (stamp, [weakref.ref(t, _drop) for t in parts], (wg, s, c))
+    return wg, s, c
+
+
 def pinned_compute_copies(params):
     """(key, parameter, copy) of every cached compute copy of the given parameters: the buffers a captured graph
     reads the weights from."""
@@ -186,6 +224,7 @@ def clear_cast_cache():
     """Drop every cached compute copy (call after parameters were changed behind autograd's back,
     e.g. by the fused optimizer kernel)."""
     _cast_cache.clear()
+    _fold_cache.clear()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -776,7 +815,22 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-class AttnBlockFn(torch.autograd.Function):
+class _BlockFn(torch.autograd.Function):
+    """Base of the two sub-block nodes.  forward() always runs with grad mode off and ctx.needs_input_grad only
+    mirrors requires_grad of the inputs, so whether a graph is being built is sampled where apply() is called."""
+    _grad_mode = True
+
+    @classmethod
+    def apply(cls, *args):
+        _BlockFn._grad_mode = torch.is_grad_enabled()
+        return super().apply(*args)
+
+    @staticmethod
+    def builds_no_graph(ctx):
+        return not (_BlockFn._grad_mode and any(ctx.needs_input_grad))
+
+
+class AttnBlockFn(_BlockFn):
     """[LayerNorm ->] to_qkv (+ optional bias, tim/models/vision_transformer.py:74) ->
     softmax(q k^T * scale) v -> [to_out] [+ x]  (mymodel/ViT.py:58, 93-104, 119) as one autograd node.
 
@@ -794,6 +848,25 @@ class AttnBlockFn(torch.autograd.Function):
         inner = w_qkv.shape[0] // 3
         dh = inner // heads
         whole = ln_w is not None and add_residual and w_out is not None and x2.is_contiguous()
+        if (whole and _infer_fusion and cdt == torch.bfloat16 and _BlockFn.builds_no_graph(ctx) and D % 8 == 0
+                and inner % 8 == 0):
+            # no autograd graph is being built: LayerNorm folded into the qkv product, nothing saved
+            wg, sq, cq = folded_linear(w_qkv, ln_w, ln_b, b_qkv)
+            dev = x2.device
+            o_probs = torch.empty((B, heads, N, N), dtype=cdt, device=dev) if want_probs else None
+            y = torch.empty((B * N, D), dtype=cdt, device=dev)
+            key = ("attn_infer", B, N, D, heads, dh)
+            nbytes = _block_ws_bytes.get(key)
+            if nbytes is None:
+                nbytes = _block_ws_bytes[key] = int(lib.vitmi_attn_block_infer_workspace_bytes(B, N, D, heads, dh))
+            ws = _ws(nbytes, dev)
+            check(lib.vitmi_attn_block_infer(B, N, D, heads, dh, _p(x2), eps, _p(wg), _p(cq), _p(sq),
+                                             _p(compute_copy(w_out, cdt)),
+                                             _p(b_out.detach().float()) if b_out is not None else None, _p(o_probs),
+                                             _p(y), _p(ws), _stream()), "vitmi_attn_block_infer")
+            if o_probs is not None:
+                ctx.mark_non_differentiable(o_probs)
+            return y.view(B, N, -1), o_probs
         if whole:                       # the usual pre-norm residual block: one foreign call for the four launches
             g = ln_w.detach().float()
             rows, dev, f32 = B * N, x2.device, torch.float32
@@ -928,7 +1001,7 @@ class AttnBlockFn(torch.autograd.Function):
         return dx, dg, db, dwq, dwo, dbo, None, None, None, None, None, dbq
 
 
-class FFBlockFn(torch.autograd.Function):
+class FFBlockFn(_BlockFn):
     """[LayerNorm ->] Linear -> GELU(erf) -> Linear [+ x]  (mymodel/ViT.py:58, 65-73, 120)."""
 
     @staticmethod
@@ -940,6 +1013,21 @@ class FFBlockFn(torch.autograd.Function):
         if x2.dtype != cdt:
             x2 = cast(x2, cdt)
         whole = ln_w is not None and add_residual and x2.is_contiguous() and drop is None
+        if (whole and _infer_fusion and cdt == torch.bfloat16 and _BlockFn.builds_no_graph(ctx)
+                and x2.shape[1] % 8 == 0 and w1.shape[0] % 8 == 0):
+            # no autograd graph is being built: LayerNorm folded into the first product, no GELU derivative stored
+            wg, s1, c1 = folded_linear(w1, ln_w, ln_b, b1)
+            rows, D = x2.shape
+            M = w1.shape[0]
+            y = torch.empty((rows, D), dtype=cdt, device=x2.device)
+            key = ("ff_infer", rows, D, M)
+            nbytes = _block_ws_bytes.get(key)
+            if nbytes is None:
+                nbytes = _block_ws_bytes[key] = int(lib.vitmi_ff_block_infer_workspace_bytes(rows, D, M))
+            ws = _ws(nbytes, x2.device)
+            check(lib.vitmi_ff_block_infer(rows, D, M, _p(x2), eps, _p(wg), _p(c1), _p(s1), _p(compute_copy(w2, cdt)),
+                                           _p(b2.detach().float()), _p(y), _p(ws), _stream()), "vitmi_ff_block_infer")
+            return y.view(*shape[:-1], w2.shape[0])
         if whole:                       # the usual pre-norm residual block: one foreign call for the three launches
             g = ln_w.detach().float()
             rows, D = x2.shape
