@@ -151,6 +151,26 @@ def test_weight_gradient_pair(ops, T, Pa, Qa, Pb, Qb):
     assert rel_err(dwa, sa) < 1e-5 and rel_err(dwb, sb) < 1e-5
 
 
+@pytest.mark.parametrize("reserved", [8, 16, 64])
+def test_weight_gradient_pair_with_reserved_compute_units(ops, reserved):
+    """vitmi_set_reserved_cus shrinks the grid the pair launch plans for (data-parallel runs leave compute units to the
+    collective): other slab counts and remainder runs, same products."""
+    from visiontransformer_amd._lib import check, lib
+    T = 12608
+    dya, xa, dyb, xb = rnd(T, 768, seed=21), rnd(T, 3072, seed=22), rnd(T, 3072, seed=23), rnd(T, 768, seed=24)
+    args = [t.to(DEV, BF) for t in (dya, xa, dyb, xb)]
+    try:
+        check(lib.vitmi_set_reserved_cus(reserved), "vitmi_set_reserved_cus")
+        dwa, dwb = ops.linear_bwd_w_pair(*args)
+        dwc, dwd = ops.linear_bwd_w_pair(args[0][:, :768], args[0], args[2][:, :2304].contiguous(), args[3])
+    finally:
+        check(lib.vitmi_set_reserved_cus(0), "vitmi_set_reserved_cus")
+    assert rel_err(dwa, q(dya).double().t() @ q(xa).double()) < 1e-4
+    assert rel_err(dwb, q(dyb).double().t() @ q(xb).double()) < 1e-4
+    assert rel_err(dwc, q(dya).double().t() @ q(dya).double()) < 1e-4
+    assert rel_err(dwd, q(dyb[:, :2304]).double().t() @ q(xb).double()) < 1e-4
+
+
 def test_vit_b16_block_at_batch_128_against_oracle():
     """One ViT-B/16 encoder block (mymodel/ViT.py:93-121 with D 768, H 12, dh 64, mlp 3072) at batch 128, bf16:
     25216 token rows, so qkv / out / fc1 / fc2 and their input gradients have 297-1188 output tiles and run on
