@@ -174,8 +174,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("VITMI_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
         if backend == "nccl":
-            # the collectives' kernels go on a high-priority stream: the GEMMs keep every CU full (one 512-thread
-            # workgroup with the whole register file per CU), so an all-reduce only advances when a CU frees up
+            # The GEMMs and the attention backward keep every CU full (one workgroup with most of the register file
+            # and LDS per CU), and a collective's workgroups cannot share a CU with them: every CU a collective
+            # holds delays one block of the next persistent launch until the others have finished.  So the
+            # collective gets as many channels (one workgroup each) as the kernels leave compute units free
+            # (VITMI_RESERVE_CUS, default 8 = one per XCD; 343 MB of gradients per step need a small fraction of
+            # the links' bandwidth), and runs on a high-priority stream.
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("VITMI_RESERVE_CUS", "8") or "8")
             opts = None
             try:
                 opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
@@ -209,7 +214,7 @@ def main():
         # VITMI_RESERVE_CUS=k keeps k compute units free of the persistent GEMMs for the collective's workgroups
         reducer = GradReducer(model, bucket_mb=int(os.environ.get("VITMI_BUCKET_MB", "64")), average=False,
                               dtype=torch.bfloat16 if os.environ.get("VITMI_BUCKET_DTYPE", "fp32") == "bf16"
-                              else torch.float32, reserve_cus=int(os.environ.get("VITMI_RESERVE_CUS", "0")))
+                              else torch.float32, reserve_cus=int(os.environ.get("VITMI_RESERVE_CUS", "8")))
     opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=5e-5)
 
     torch.manual_seed(1234 + rank)
@@ -362,7 +367,8 @@ def main():
             # what the data-parallel exchange was: ranks in the process group (RCCL when the backend is nccl),
             # buckets and bytes per step
             "exchange": (dict(reducer.info(), rccl_ranks=dist.get_world_size()
-                              if "nccl" in str(dist.get_backend()).lower() else 0) if reducer is not None else None),
+                              if "nccl" in str(dist.get_backend()).lower() else 0,
+                              rccl_max_nchannels=os.environ.get("NCCL_MAX_NCHANNELS")) if reducer is not None else None),
             "roofline": roof,
             "cpu_baseline": cpu,
         }

@@ -300,6 +300,23 @@ def test_attention_backward_one_kernel_bf16(ops, B, N, H, DH):
         lib.vitmi_debug_set_attn_bwd_fused(2)
 
 
+def test_attention_backward_one_kernel_with_reserved_compute_units(ops):
+    # vitmi_set_reserved_cus leaves compute units to a collective: the one-workgroup-per-CU backward launches that many
+    # fewer workgroups and each walks more pairs; same gradients bit for bit
+    from visiontransformer_amd._lib import check, lib
+    B, N, H, DH = 64, 197, 12, 64
+    qd = rnd(B, N, 3 * H * DH, seed=9, scale=1.5).to(DEV, torch.bfloat16)
+    dod = rnd(B, N, H * DH, seed=10).to(DEV, torch.bfloat16)
+    o, lse, _ = ops.attn_fwd(qd, B, N, H, DH, False)
+    full = ops.attn_bwd(qd, o, dod, lse, B, N, H, DH).clone()
+    try:
+        for k in (8, 64):
+            check(lib.vitmi_set_reserved_cus(k), "vitmi_set_reserved_cus")
+            assert torch.equal(full, ops.attn_bwd(qd, o, dod, lse, B, N, H, DH)), k
+    finally:
+        check(lib.vitmi_set_reserved_cus(0), "vitmi_set_reserved_cus")
+
+
 def test_attention_rejects_long_sequences(ops):
     from visiontransformer_amd._lib import VitmiError
     with pytest.raises(VitmiError, match="not supported"):

@@ -24,6 +24,8 @@
 
 #include "common.h"
 
+int vitmi_reserved_cus();   // gemm_fast.hip
+
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
@@ -1536,6 +1538,12 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     return launch_bwd_t<DH, NC, 1>(qkv, out, dout, lse, delta, dqkv, B, N, H, s);
 }
 
+// compute units the one-workgroup-per-CU kernels may fill: all but those vitmi_set_reserved_cus keeps for a collective
+inline int fused_grid_limit(int cus) {
+    const int left = cus - vitmi_reserved_cus();
+    return left > 8 ? left : 8;
+}
+
 // one-kernel backward: heads of 64, 129..208 tokens (9..13 key tiles: the owners, with waves 13..15 on dQ).
 // 0 = the dQ + dK/dV pair, 1 = one kernel, 2 = one kernel, operands of the next pair fetched under the current one
 // where that variant applies (193..208 tokens).  At B 256 / N 197 / H 12: 260 / 231 / 214 us per launch.
@@ -1553,6 +1561,7 @@ int launch_bwd_fused_t(const void* qkv, const void* out, const void* dout, const
     if (rc != VITMI_OK) return rc;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    cus = fused_grid_limit(cus);
     const int grid = B * H < cus ? B * H : cus;     // one workgroup fills a compute unit
     hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<NC>), dim3(grid), dim3(FUSED_THREADS), sm, s, (const bf16_t*)qkv,
                        (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, B * H, scale);
@@ -1567,6 +1576,7 @@ int launch_bwd_pipe(const void* qkv, const void* out, const void* dout, const fl
     if (rc != VITMI_OK) return rc;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+    cus = fused_grid_limit(cus);
     const int grid = B * H < cus ? B * H : cus;     // one workgroup fills a compute unit
     hipLaunchKernelGGL(attn_bwd_pipe_bf16_kernel, dim3(grid), dim3(FUSED_THREADS), PIPE_LDS, s, (const bf16_t*)qkv,
                        (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, B * H, scale);

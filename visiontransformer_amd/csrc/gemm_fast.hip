@@ -1359,6 +1359,8 @@ extern "C" int vitmi_set_reserved_cus(int k) {
     return VITMI_OK;
 }
 
+int vitmi_reserved_cus() { return g_reserved_cus; }
+
 // persistent blocks of the phased nt kernel: one per CU, rounded down to a multiple of 8 so that a
 // block's tiles stay on its XCD, minus the reserved ones
 static int phased_grid_blocks() {
