@@ -178,9 +178,9 @@ def main():
             # and LDS per CU), and a collective's workgroups cannot share a CU with them: every CU a collective
             # holds delays one block of the next persistent launch until the others have finished.  So the
             # collective gets as many channels (one workgroup each) as the kernels leave compute units free
-            # (VITMI_RESERVE_CUS, default 8 = one per XCD; 343 MB of gradients per step need a small fraction of
+            # (VITMI_RESERVE_CUS, default 16 = two per XCD; 343 MB of gradients per step need a small fraction of
             # the links' bandwidth), and runs on a high-priority stream.
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("VITMI_RESERVE_CUS", "8") or "8")
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("VITMI_RESERVE_CUS", "16") or "16")
             opts = None
             try:
                 opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
@@ -214,7 +214,7 @@ def main():
         # VITMI_RESERVE_CUS=k keeps k compute units free of the persistent GEMMs for the collective's workgroups
         reducer = GradReducer(model, bucket_mb=int(os.environ.get("VITMI_BUCKET_MB", "64")), average=False,
                               dtype=torch.bfloat16 if os.environ.get("VITMI_BUCKET_DTYPE", "fp32") == "bf16"
-                              else torch.float32, reserve_cus=int(os.environ.get("VITMI_RESERVE_CUS", "8")))
+                              else torch.float32, reserve_cus=int(os.environ.get("VITMI_RESERVE_CUS", "16")))
     opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=5e-5)
 
     torch.manual_seed(1234 + rank)
