@@ -29,6 +29,26 @@ for dt in (_lib.F32, _lib.BF16):
     lib.vitmi_attn_bwd_workspace_bytes(dt, big, 608, 64, 64)
     lib.vitmi_attn_bwd_dprobs_workspace_bytes(dt, 4096, 256, 64, 64)
     lib.vitmi_patch_embed_bwd_w_workspace_bytes(dt, 4096, 3, 224, 224, 16, 768)
+# the paired weight gradients: plan arithmetic for the benchmark's pairs, with compute units reserved, for shapes that
+# fall back to single products, and at the largest token counts
+for res in (0, 8, 64, 128):
+    assert lib.vitmi_set_reserved_cus(res) == 0
+    assert lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.BF16, 50432, 768, 3072, 3072, 768) > 0
+    assert lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.BF16, 50432, 768, 768, 2304, 768) > 0
+    lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.BF16, big - 63, 768, 768, 2304, 768)
+    lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.BF16, 64 * 40, 256, 256, 256, 256)
+    lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.BF16, 50432, 32768, 32768, 32768, 32768)
+assert lib.vitmi_set_reserved_cus(0) == 0
+assert lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.BF16, 50400, 768, 768, 2304, 768) >= 0
+assert lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.F32, 50432, 768, 768, 2304, 768) == 0
+assert lib.vitmi_gemm_wgrad_pair(_lib.BF16, 64, 256, 256, None, 256, None, 256, None, 256, 256, None, 256, None, 256, None,
+                                 None, None) != 0
+assert lib.vitmi_attn_block_infer_workspace_bytes(256, 197, 768, 12, 64) > 0
+assert lib.vitmi_attn_block_infer_workspace_bytes(big // 608, 608, 768, 12, 64) > 0
+assert lib.vitmi_ff_block_infer_workspace_bytes(50432, 768, 3072) > 0
+assert lib.vitmi_ff_block_infer_workspace_bytes(big, 4096, 16384) > 0
+assert lib.vitmi_gemm_ln(0, 1, 1, None, 0, None, None, None, None, None, None, 0, 5, None) != 0
+assert lib.vitmi_row_stats(None, 0, None, None, _lib.BF16, 1, 1, 1e-5, None) != 0
 assert lib.vitmi_gemm_colsum_workspace_bytes(50432, 3072) > 0
 assert lib.vitmi_colsum_workspace_bytes(2 ** 40, 4096) > 0
 assert lib.vitmi_layernorm_bwd_workspace_bytes(2 ** 40, 1024) > 0
@@ -40,7 +60,7 @@ assert lib.vitmi_attn_bwd(None, None, None, None, None, None, None, _lib.BF16, 1
 assert lib.vitmi_set_reserved_cus(7) != 0 and b"multiple of 8" in lib.vitmi_last_error()
 assert lib.vitmi_set_reserved_cus(0) == 0
 for knob in ("vitmi_debug_set_nt_group", "vitmi_debug_set_nt_tail_split", "vitmi_debug_set_gelu_pair",
-             "vitmi_debug_set_attn_head_groups"):
+             "vitmi_debug_set_attn_head_groups", "vitmi_debug_set_tn_batch"):
     getattr(lib, knob)(1)
 print("host-sanitized checks ok")
 """

@@ -1715,7 +1715,7 @@ static bool tn_batch_plan(int n, const int* P, const int* Q, int T, TnBatch* tb)
     }
     const int G = phased_grid_blocks(), nk = T / TK;
     const int nmain = G / tiles;
-    if (nmain < 1 || nk < 4 * (nmain + 1)) return false;
+    if (nmain < 1 || nk < 4 * (nmain + 1) || (long long)tiles * nk >= (1ll << 31)) return false;   // unit indices are ints
     const int rem = G - nmain * tiles;
     int a = ceil_div(nk, nmain), r = 0, upl = 1;
     // Blocks left over take the last r token tiles of m whole output tiles each, so that all of them walk the same
