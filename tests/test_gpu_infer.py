@@ -124,3 +124,28 @@ def test_inference_blocks_leave_training_alone():
     assert out.requires_grad
     out.float().sum().backward()
     assert all(p.grad is not None for n, p in m.named_parameters() if "unk" not in n and "mask" not in n)
+
+
+def test_folded_operands_follow_the_fused_optimizer():
+    """FusedAdam rewrites the parameters through raw pointers (their version counters do not move): the folded
+    operands of the inference entry points must not survive a step."""
+    from visiontransformer_amd import ops
+    from visiontransformer_amd.optim import FusedAdam
+    g = Golden("cifar_dh8")
+    m = build(g, True)
+    opt = FusedAdam(m.parameters(), lr=3e-2)
+    with torch.no_grad():
+        before = run(m, g)
+    m.train()
+    torch.nn.functional.cross_entropy(run(m, g), g.y.to(DEV)).backward()
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        fused = run(m, g)
+        prev = ops.set_inference_fusion(False)
+        try:
+            plain = run(m, g)
+        finally:
+            ops.set_inference_fusion(prev)
+    assert rel_err(fused, plain) < 2e-2
+    assert rel_err(before, plain) > 0.1          # the step moved the logits far beyond that bar

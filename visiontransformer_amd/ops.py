@@ -167,6 +167,11 @@ def set_inference_fusion(on):
     return prev
 
 
+def drop_folded():
+    """Forget every folded operand (call after parameters were changed without a version bump)."""
+    _fold_cache.clear()
+
+
 def folded_linear(w, ln_w, ln_b, b):
     parts = [t for t in (w, ln_w, ln_b, b) if t is not None]
     key = tuple(id(t) for t in (w, ln_w, ln_b, b))

@@ -89,6 +89,9 @@ class FusedAdam:
     @torch.no_grad()
     def step(self, grad_scale=1.0):
         self.step_count += 1
+        # the kernel writes the parameters through raw pointers (no version bump): operands derived from them that
+        # it does not refresh itself (LayerNorm folded into a weight, for the inference entry points) are dropped
+        ops.drop_folded()
         launches = {}                # (device, group index, step number) -> parameters
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
