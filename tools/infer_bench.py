@@ -35,3 +35,12 @@ for on in (False, True):
     t = min(res[on])
     print(f"inference entry points {'on ' if on else 'off'}: {t:.3f} ms per forward, {B / t * 1e3:.0f} images/s", flush=True)
 print(f"logits on vs off: {err:.2e} relative")
+import json  # noqa: E402
+t = min(res[True])
+gflop = 2 * 17.563137024                      # forward GFLOP per image (2 x MACs)
+print(json.dumps({"metric": "inference images/sec ViT-B/16 224px (forward only, torch.no_grad)", "value": B / t * 1e3,
+                  "unit": "images/s", "n_gpus": 1, "ms_per_step": t, "higher_is_better": True, "dtype": "bf16",
+                  "data": "synthetic", "config": {"workload": f"vit_b16_224 forward, batch {B}", "global_batch": B,
+                                                  "seq_len": 197},
+                  "fwd_mfma_frac": B / t * 1e3 * gflop / 1e3 / 2500.0,
+                  "training_forward_ms": min(res[False])}))
