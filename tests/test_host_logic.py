@@ -175,3 +175,15 @@ def test_presets_build_the_reference_geometries(tmp_path):
     assert merged.patch.depth == 5 and merged.patch.heads == 2 and merged.general.seed == 1
     merged.set_subkey("patch", "heads", 4)
     assert merged.values_()["patch"]["heads"] == 4
+
+
+def test_the_library_is_loaded_after_torch():
+    """A process that imports this package before torch must still end up with ONE HIP runtime: _lib imports torch
+    (which ships its own copy of the runtime) before it loads libvitmi_hip.so."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import visiontransformer_amd._lib as l; "
+            "assert 'torch' in sys.modules; print('ok', l.lib.vitmi_version())" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout, r.stderr[-1500:])

@@ -7,6 +7,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_longlong, c_void_p
 
+# torch first: it ships its own copy of the HIP runtime, and the library has to bind to the copy torch's streams and
+# allocations live in.  Loaded the other way round the process holds two runtimes and every launch of this library
+# fails with "no ROCm-capable device is detected".
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # VITMI_LIB: another build of the same library, for A/B timing of kernel versions on one box (tools/)
 LIB_PATH = os.environ.get("VITMI_LIB") or os.path.join(_HERE, "libvitmi_hip.so")
