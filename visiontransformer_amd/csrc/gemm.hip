@@ -599,12 +599,14 @@ extern "C" int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long
 
 extern "C" long long vitmi_gemm_wgrad_pair_workspace_bytes(int dt, int T, int P0, int Q0, int P1, int Q1) {
     const int P[2] = {P0, P1}, Q[2] = {Q0, Q1};
-    if (dt == VITMI_BF16) {
-        const long long b = vitmi_gemm_tn_batch_bytes(2, P, Q, T);
-        if (b > 0) return b;
-    }
+    // enough for either route: operands that turn out to be misaligned at call time take the two single products
     const long long w0 = vitmi_gemm_wgrad_workspace_bytes(dt, P0, Q0, T), w1 = vitmi_gemm_wgrad_workspace_bytes(dt, P1, Q1, T);
-    return w0 > w1 ? w0 : w1;
+    long long b = w0 > w1 ? w0 : w1;
+    if (dt == VITMI_BF16) {
+        const long long pair = vitmi_gemm_tn_batch_bytes(2, P, Q, T);
+        if (pair > b) b = pair;
+    }
+    return b;
 }
 
 extern "C" int vitmi_gemm_wgrad_pair(int dt, int T, int P0, int Q0, const void* U0, long long ldu0, const void* V0,
