@@ -70,3 +70,28 @@ def test_hip_model_against_reference_vectors(name, dtype, tol):
     loss.backward()
     worst = max((rel_err(p.grad, c.grads[k]), k) for k, p in m.named_parameters())
     assert worst[0] < tol, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_model_without_autograd_graph_against_reference_vectors(name):
+    """model.eval() under torch.no_grad() (the evaluation and attack scripts' mode): qkv WITH bias and LayerNorm eps
+    1e-6 through the folded products of vitmi_attn_block_infer / vitmi_ff_block_infer; logits, features and the
+    probabilities a hook on attn_drop sees against the reference class's, bf16 bar."""
+    from visiontransformer_amd.vision_transformer import VisionTransformer
+    c = Case(name)
+    m = VisionTransformer(**c.kw)
+    m.load_state_dict(c.params, strict=True)
+    m = m.to(DEV).set_compute_dtype(torch.bfloat16).eval()
+    seen = []
+    hooks = [mod.register_forward_hook(lambda mm, i, o: seen.append(o.detach().float().cpu()))
+             for n, mod in m.named_modules() if "attn_drop" in n]
+    unk = c.unk.to(DEV) if c.unk is not None else None
+    with torch.no_grad():
+        feat = m.forward_features(c.x.to(DEV), unk)
+        n_probs = len(seen)
+        logits = m(c.x.to(DEV), unk_mask=unk) if unk is not None else m(c.x.to(DEV))
+    for h in hooks:
+        h.remove()
+    assert rel_err(feat, c.features) < 2e-2 and rel_err(logits, c.logits) < 2e-2
+    assert n_probs == len(c.probs) and all(rel_err(a, b) < 2e-2 for a, b in zip(seen[:n_probs], c.probs))
