@@ -212,7 +212,9 @@ def main():
         broadcast_parameters(model, src=0)
         # the 1/world factor rides on the Adam kernel.  VITMI_BUCKET_DTYPE=bf16 halves the bytes on the links,
         # VITMI_RESERVE_CUS=k keeps k compute units free of the persistent GEMMs for the collective's workgroups
-        reducer = GradReducer(model, bucket_mb=int(os.environ.get("VITMI_BUCKET_MB", "64")), average=False,
+        # buckets of one encoder layer each (28 MB of fp32 gradients; a bucket closes at >= 24 MiB): what is still on
+        # the links when backward ends is the first layer's bucket, not the last three layers' of a 64 MiB bucket
+        reducer = GradReducer(model, bucket_mb=int(os.environ.get("VITMI_BUCKET_MB", "24")), average=False,
                               dtype=torch.bfloat16 if os.environ.get("VITMI_BUCKET_DTYPE", "fp32") == "bf16"
                               else torch.float32, reserve_cus=int(os.environ.get("VITMI_RESERVE_CUS", "16")))
     opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=5e-5)
