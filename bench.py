@@ -180,7 +180,8 @@ def main():
             # collective gets as many channels (one workgroup each) as the kernels leave compute units free
             # (VITMI_RESERVE_CUS, default 16 = two per XCD; 343 MB of gradients per step need a small fraction of
             # the links' bandwidth), and runs on a high-priority stream.
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("VITMI_RESERVE_CUS", "16") or "16")
+            if int(os.environ.get("VITMI_RESERVE_CUS", "16") or 0) > 0:
+                os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("VITMI_RESERVE_CUS", "16"))
             opts = None
             try:
                 opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
@@ -216,7 +217,7 @@ def main():
         # the links when backward ends is the first layer's bucket, not the last three layers' of a 64 MiB bucket
         reducer = GradReducer(model, bucket_mb=int(os.environ.get("VITMI_BUCKET_MB", "24")), average=False,
                               dtype=torch.bfloat16 if os.environ.get("VITMI_BUCKET_DTYPE", "fp32") == "bf16"
-                              else torch.float32, reserve_cus=int(os.environ.get("VITMI_RESERVE_CUS", "16")))
+                              else torch.float32, reserve_cus=int(os.environ.get("VITMI_RESERVE_CUS", "16") or 0))
     opt = FusedAdam(model.parameters(), lr=1e-3, betas=(0.9, 0.99), weight_decay=5e-5)
 
     torch.manual_seed(1234 + rank)
