@@ -149,3 +149,29 @@ def test_folded_operands_follow_the_fused_optimizer():
             ops.set_inference_fusion(prev)
     assert rel_err(fused, plain) < 2e-2
     assert rel_err(before, plain) > 0.1          # the step moved the logits far beyond that bar
+
+
+@pytest.mark.parametrize("case", ["cifar_dh8", "mask_dh8", "n197_dh64"])
+def test_graphed_inference_replays_the_eager_forward(case):
+    """GraphedInference: the no-grad forward captured once and replayed on new inputs, bit for bit the eager result;
+    after the weights change, refresh() captures again."""
+    from visiontransformer_amd.graphs import GraphedInference
+    g = Golden(case)
+    m = build(g, False)
+    x = g.x.to(DEV)
+    um = g.unk_mask.to(DEV) if (g.module != "ViT" and g.unk_mask is not None) else None
+    gi = GraphedInference(m, torch.zeros_like(x), um)
+    with torch.no_grad():
+        eager = m(x, unk_mask=um) if um is not None else m(x)
+    got = gi(x, um).clone()
+    assert torch.equal(got, eager) and rel_err(got, g.logits) < 2e-2
+    x2 = x.flip(0) * 0.5
+    with torch.no_grad():
+        eager2 = m(x2, unk_mask=um) if um is not None else m(x2)
+    assert torch.equal(gi(x2, um), eager2)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(0.9)
+        eager3 = m(x, unk_mask=um) if um is not None else m(x)
+    gi.refresh()
+    assert torch.equal(gi(x, um), eager3)
