@@ -144,10 +144,18 @@ int vitmi_debug_set_nt_group(int gm);
  * one tile fewer than the busiest ones (all_blocks != 0: every block) start up to span (by position inside the
  * XCD) + xspan (by XCD) ticks late.  0, 0 = off.  Process-wide; for benchmarking only. */
 int vitmi_debug_set_nt_stagger(int span_ticks, int xspan_ticks, int all_blocks);
-/* Epilogue pair of vitmi_ff_block_fwd/bwd: 0 (default) = VITMI_EPI_GELU_D / VITMI_EPI_MULAUX, 1 = VITMI_EPI_GELU /
- * VITMI_EPI_DGELU.  Process-wide and to be left alone between a forward pass and its backward pass; for
- * benchmarking and error studies only. */
-int vitmi_debug_set_gelu_pair(int classic);
+/* How the bf16 MLP block evaluates nn.GELU() (mymodel/ViT.py:67, the exact erf form) and its derivative; the fp32
+ * kernels always call erff.  Process-wide; leave it alone between a forward pass and its backward pass.
+ *   0 "fast" (default): VITMI_EPI_GELU_D / VITMI_EPI_MULAUX.  The forward epilogue evaluates gelu and gelu' together
+ *      through Phi(x) ~ 1 / (1 + exp(-x q(x^2))), q a fitted even polynomial: |gelu error| <= 3.8e-5,
+ *      |gelu' error| <= 9.3e-5 against the erf forms, before the values are rounded to bf16 (8 significant bits,
+ *      relative 3.9e-3) and IEEE half (11 bits); the backward multiplies by the stored derivative.
+ *   1 "erf": VITMI_EPI_GELU / VITMI_EPI_DGELU.  gelu through Abramowitz-Stegun 7.1.26 erf (|error| <= 1.5e-7), the
+ *      pre-activation is stored in bf16 and the backward evaluates the erf-form derivative from it.
+ * The Python side exposes it as visiontransformer_amd.set_gelu("fast" | "erf") and model.set_gelu(...). */
+int vitmi_set_gelu_mode(int erf_pair);
+int vitmi_get_gelu_mode(void);
+int vitmi_debug_set_gelu_pair(int classic);     /* older name of vitmi_set_gelu_mode */
 /* 1 (default): when the persistent nt kernel's last round would fill less than half of the compute units, the
  * rows of that round run as a second launch of the 128 x 128 kernel; 0: one launch.  Process-wide; benchmarking. */
 int vitmi_debug_set_nt_tail_split(int on);
@@ -359,6 +367,11 @@ int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, const void*
  * operands are made once per weight version by the caller.  probs and b_out may be NULL. */
 int vitmi_row_stats(const void* x, long long ldx, float* mean, float* rstd, int dt, long long rows, int D, float eps,
                     void* stream);
+/* The folded operands of vitmi_gemm_ln from the fp32 parameters (nn.LayerNorm weight / bias of mymodel/ViT.py:55 and the
+ * nn.Linear behind it, :66 / :86): w [N,K], gamma / beta [K], bias [N] or NULL -> w_folded bf16 [N,K], w_rowsum [N],
+ * bias_folded [N].  Weight preparation: one launch per weight version. */
+int vitmi_fold_ln(const float* w, const float* gamma, const float* beta, const float* bias, void* w_folded,
+                  float* w_rowsum, float* bias_folded, int N, int K, void* stream);
 int vitmi_gemm_ln(int M, int N, int K, const void* x, long long ldx, const void* w_folded, const float* bias_folded,
                   const float* w_rowsum, const float* mean, const float* rstd, void* C, long long ldc, int epilogue,
                   void* stream);

@@ -223,3 +223,40 @@ def test_vit_b16_full_depth_against_oracle(dtype, tol, B):
     assert abs(loss.item() - loss_ref.item()) < tol * max(1.0, abs(loss_ref.item()))
     errs = sorted(((rel_err(p.grad, grads_ref[k]), k) for k, p in m.named_parameters()), reverse=True)
     assert errs[0][0] < tol, errs[:5]
+
+
+@pytest.mark.parametrize("T,P0,Q0,P1,Q1", [(50432, 384, 1536, 1536, 384), (50432, 768, 3072, 3072, 768),
+                                            (50432, 768, 768, 2304, 768), (12608, 384, 384, 1152, 384)])
+def test_weight_gradient_workspace_holds_under_every_cu_reservation(T, P0, Q0, P1, Q1):
+    """A workspace sized while a CU reservation was in force (GradReducer attached) must hold after the reservation
+    is gone (more slabs / slots per tile): the launches stay inside the queried bytes -- a guard region behind the
+    workspace is untouched -- and give the same gradients."""
+    from visiontransformer_amd import ops
+    from visiontransformer_amd._lib import check, lib
+    g = torch.Generator().manual_seed(T + P0)
+    dya = (torch.randn(T, P0, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    xa = torch.randn(T, Q0, generator=g).to(DEV, torch.bfloat16)
+    dyb = (torch.randn(T, P1, generator=g) * 0.1).to(DEV, torch.bfloat16)
+    xb = torch.randn(T, Q1, generator=g).to(DEV, torch.bfloat16)
+    results = []
+    try:
+        for size_at, run_at in ((16, 0), (0, 32), (128, 0), (0, 0)):
+            check(lib.vitmi_set_reserved_cus(size_at))
+            nbytes = int(lib.vitmi_gemm_wgrad_pair_workspace_bytes(1, T, P0, Q0, P1, Q1))
+            guard = 1 << 20
+            ws = torch.empty(nbytes + guard, dtype=torch.uint8, device=DEV)
+            ws[nbytes:] = 0xA5
+            check(lib.vitmi_set_reserved_cus(run_at))
+            dwa = torch.empty(P0, Q0, device=DEV)
+            dwb = torch.empty(P1, Q1, device=DEV)
+            p = ops._p
+            check(lib.vitmi_gemm_wgrad_pair(1, T, P0, Q0, p(dya), P0, p(xa), Q0, p(dwa), P1, Q1, p(dyb), P1, p(xb), Q1,
+                                            p(dwb), p(ws), ops._stream()), "vitmi_gemm_wgrad_pair")
+            check(lib.vitmi_gemm_wgrad(1, P0, Q0, T, p(dya), P0, p(xa), Q0, p(dwa), Q0, p(ws), ops._stream()))
+            torch.cuda.synchronize()
+            assert bool((ws[nbytes:] == 0xA5).all()), (size_at, run_at)
+            results.append((dwa.clone(), dwb.clone()))
+    finally:
+        check(lib.vitmi_set_reserved_cus(0))
+    for a, b in results[1:]:
+        assert rel_err(a, results[0][0]) < 1e-5 and rel_err(b, results[0][1]) < 1e-5

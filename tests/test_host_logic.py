@@ -187,3 +187,65 @@ def test_the_library_is_loaded_after_torch():
             "assert 'torch' in sys.modules; print('ok', l.lib.vitmi_version())" % root)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout, r.stderr[-1500:])
+
+
+def test_workspace_sizes_do_not_depend_on_the_cu_reservation():
+    """Callers cache the workspace size of a shape; vitmi_set_reserved_cus (a GradReducer attached or removed) and the
+    debug switches change how the weight-gradient launches split their tokens, so a size answered under one setting
+    must hold under every other: the queries plan with the whole chip."""
+    lib = _lib.lib
+    shapes_ff = [(50432, 768, 3072), (50432, 384, 1536), (16640, 192, 512), (1970, 768, 3072)]
+    shapes_attn = [(256, 197, 768, 12, 64), (256, 197, 384, 6, 64), (256, 65, 192, 12, 8)]
+
+    def sizes():
+        out = [lib.vitmi_ff_block_bwd_workspace_bytes(1, *s) for s in shapes_ff]
+        out += [lib.vitmi_attn_block_bwd_workspace_bytes(1, *s) for s in shapes_attn]
+        out += [lib.vitmi_gemm_wgrad_workspace_bytes(1, 768, 768, 50432), lib.vitmi_gemm_wgrad_workspace_bytes(1, 384, 1536, 50432),
+                lib.vitmi_gemm_wgrad_pair_workspace_bytes(1, 50432, 768, 3072, 3072, 768),
+                lib.vitmi_patch_embed_bwd_w_workspace_bytes(1, 256, 3, 224, 224, 16, 768)]
+        return out
+
+    base = sizes()
+    assert all(b > 0 for b in base)
+    try:
+        for k in (8, 16, 32, 64, 128):
+            assert lib.vitmi_set_reserved_cus(k) == 0
+            assert sizes() == base, k
+        lib.vitmi_set_reserved_cus(16)
+        for knob, val in (("vitmi_debug_set_tn_batch", 0), ("vitmi_debug_set_tn_config", 0), ("vitmi_debug_set_tn_config", 1)):
+            getattr(lib, knob)(val)
+            assert sizes() == base, (knob, val)
+            getattr(lib, knob)(1 if knob.endswith("batch") else -1)
+    finally:
+        lib.vitmi_set_reserved_cus(0)
+        lib.vitmi_debug_set_tn_batch(1)
+        lib.vitmi_debug_set_tn_config(-1)
+
+
+@pytest.mark.parametrize("modname", ["ViT", "ViT_mask"])
+def test_load_vit_round_trip(tmp_path, modname):
+    """creat_VIT -> torch.save(state_dict) -> load_VIT (mymodel/ViT.py:196-211, ViT_mask.py:209-223): the reloaded
+    model holds the saved tensors bit for bit, and a checkpoint of the other class is refused (their positional
+    tables differ in shape)."""
+    from visiontransformer_amd.presets import load_preset
+    mod = getattr(vta, modname)
+    cfg = load_preset("cifar10_32x4", depth=2)
+    torch.manual_seed(5)
+    model = mod.creat_VIT(cfg)
+    path = str(tmp_path / f"{modname}_0.500.pth")
+    torch.save(model.state_dict(), path)                       # what trainer.py:213-218 writes
+    loaded = mod.load_VIT(path, cfg)
+    assert type(loaded) is type(model)
+    a, b = model.state_dict(), loaded.state_dict()
+    assert list(a) == list(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    other = vta.ViT_mask if modname == "ViT" else vta.ViT
+    with pytest.raises(RuntimeError, match="pos_embedding"):
+        other.load_VIT(path, cfg)
+
+
+def test_pbf_jigsaw_needs_the_bank_as_data():
+    from visiontransformer_amd.masking_generator import JigsawPuzzleMaskedRegion
+    with pytest.raises(ValueError, match="pub_data"):
+        JigsawPuzzleMaskedRegion(32, 4, 32, 4, mask_type="pbf", device="cpu")

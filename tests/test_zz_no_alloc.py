@@ -54,3 +54,47 @@ def test_static_scratch_rejects_rows_beyond_its_size():
     with pytest.raises(VitmiError, match="exceeds the static scratch"):
         check(lib.vitmi_layernorm_bwd_static(p(x), p(x), D, p(g), p(v), p(v), None, p(x), p(g), p(g), None, 0, 4, D,
                                              ops._stream()), "vitmi_layernorm_bwd_static")
+
+
+def test_static_scratch_call_allocates_nothing_and_runs_under_stream_capture():
+    """What the entry point exists for: the call takes no device memory (the allocator's and the driver's counts do not
+    move across it) and is legal while a stream is being captured, where hipMalloc is not; the replayed graph gives the
+    eager result bit for bit.  One eager call comes first: the first call on a device looks the array's address up
+    (hipGetSymbolAddress), one-time set-up that callers do before they start capturing, like a warm-up of any other
+    kernel."""
+    from visiontransformer_amd import ops
+    from visiontransformer_amd._lib import check, lib
+    rows, D = 4000, 768
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(rows, D, generator=g).to(DEV, torch.bfloat16)
+    dy = torch.randn(rows, D, generator=g).to(DEV, torch.bfloat16)
+    res = torch.randn(rows, D, generator=g).to(DEV, torch.bfloat16)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV)
+    _, mean, rstd = ops.layernorm_fwd(x, gamma, torch.zeros(D, device=DEV), 1e-5)
+    outs = [torch.zeros_like(x), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)]
+    p = ops._p
+
+    def call(stream):
+        check(lib.vitmi_layernorm_bwd_static(p(dy), p(x), x.stride(0), p(gamma), p(mean), p(rstd), p(res), p(outs[0]),
+                                             p(outs[1]), p(outs[2]), p(outs[3]), ops._dt(x), rows, D, stream),
+              "vitmi_layernorm_bwd_static")
+
+    call(ops._stream())
+    torch.cuda.synchronize()
+    eager = [o.clone() for o in outs]
+    free0, alloc0, reserved0 = torch.cuda.mem_get_info()[0], torch.cuda.memory_allocated(), torch.cuda.memory_reserved()
+    call(ops._stream())
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    assert torch.cuda.memory_allocated() == alloc0 and torch.cuda.memory_reserved() == reserved0
+    for o in outs:
+        o.zero_()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        call(ops._stream())                      # torch's current stream is the capturing one here
+    torch.cuda.synchronize()
+    assert all(float(o.float().abs().sum()) == 0.0 for o in outs)      # captured, not run
+    graph.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(outs, eager):
+        assert torch.equal(a, b)

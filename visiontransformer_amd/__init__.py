@@ -12,5 +12,6 @@ fallback compute path).
 from . import _lib  # noqa: F401  (fails loudly when the HIP library is absent)
 from . import ViT, ViT_ape, ViT_mask, ViT_mask_avg, dpsgd, ops  # noqa: F401
 from .masking_generator import MaskingGenerator  # noqa: F401
+from .ops import set_gelu  # noqa: F401
 
 __version__ = "0.1.0"

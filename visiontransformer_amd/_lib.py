@@ -45,6 +45,7 @@ SIGNATURES = {
     "vitmi_debug_set_tn_batch": (I, [I]),
     "vitmi_row_stats": (I, [P, L, P, P, I, L, I, F, P]),
     "vitmi_gemm_ln": (I, [I, I, I, P, L, P, P, P, P, P, P, L, I, P]),
+    "vitmi_fold_ln": (I, [P, P, P, P, P, P, P, I, I, P]),
     "vitmi_attn_block_infer_workspace_bytes": (L, [I, I, I, I, I]),
     "vitmi_attn_block_infer": (I, [I, I, I, I, I, P, F, P, P, P, P, P, P, P, P, P]),
     "vitmi_ff_block_infer_workspace_bytes": (L, [I, I, I]),
@@ -58,6 +59,8 @@ SIGNATURES = {
     "vitmi_debug_set_attn_head_groups": (I, [I]),
     "vitmi_debug_set_attn_bwd_fused": (I, [I]),
     "vitmi_debug_set_gelu_pair": (I, [I]),
+    "vitmi_set_gelu_mode": (I, [I]),
+    "vitmi_get_gelu_mode": (I, []),
     "vitmi_debug_set_nt_stagger": (I, [I, I, I]),
     "vitmi_colsum_workspace_bytes": (L, [L, I]),
     "vitmi_colsum": (I, [P, I, L, I, L, P, P, P]),

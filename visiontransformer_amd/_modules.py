@@ -280,6 +280,11 @@ class _VITBase(_HipModule):
                 m.compute_dtype = dtype
         return self
 
+    @staticmethod
+    def set_gelu(mode):
+        """"fast" (default) or "erf": see visiontransformer_amd.ops.set_gelu (a process-wide switch of the library)."""
+        return ops.set_gelu(mode)
+
     # ---- timm-style aliases used by trainer.py / mia_attn.py / vit_rollout.py ------------------
     @property
     def blocks(self):

@@ -37,10 +37,12 @@ int input_grad(int dt, int T, int K, int N, const void* dy, const void* w, const
 // which epilogue pair the MLP block runs: 0 = GELU_D / MULAUX (u holds gelu'(pre-activation)), 1 = GELU / DGELU (u
 // holds the pre-activation and the backward epilogue evaluates the derivative)
 static int g_classic_gelu_pair = 0;
-extern "C" int vitmi_debug_set_gelu_pair(int classic) {
-    g_classic_gelu_pair = classic ? 1 : 0;
+extern "C" int vitmi_set_gelu_mode(int erf_pair) {
+    g_classic_gelu_pair = erf_pair ? 1 : 0;
     return VITMI_OK;
 }
+extern "C" int vitmi_get_gelu_mode() { return g_classic_gelu_pair; }
+extern "C" int vitmi_debug_set_gelu_pair(int classic) { return vitmi_set_gelu_mode(classic); }   // older name
 extern "C" int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x, const float* gamma, const float* beta,
                                   float eps, const void* w1, const float* b1, const void* w2, const float* b2, void* xn,
                                   float* mean, float* rstd, void* u, void* h, void* y, void* stream) {

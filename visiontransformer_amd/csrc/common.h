@@ -137,6 +137,14 @@ __device__ __forceinline__ void gelu_both_fast(float x, float& g, float& dg) {
     g = x * s;
     dg = fmaf(x, t, s);
 }
+// GELU in its erf form through erf_exp_fast (|error| <= 1.5e-7 x): what VITMI_EPI_GELU evaluates, the forward half of
+// the "erf" pair
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+#pragma clang fp contract(off)
+    float er, e;
+    erf_exp_fast(x, er, e);
+    return x * fmaf(0.5f, er, 0.5f);
+}
 __device__ __forceinline__ float gelu_grad_fast(float x) {
 #pragma clang fp contract(off)
     float er, e;

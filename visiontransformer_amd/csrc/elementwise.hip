@@ -1015,6 +1015,44 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const T* __restrict__ x,
     }
 }
 
+// Folds LayerNorm's affine parameters into the weight of the Linear behind it (operands of vitmi_gemm_ln): one wave
+// per weight row n; wg[n][k] = bf16(w[n][k] * gamma[k]), s[n] = sum_k float(wg[n][k]) (of the ROUNDED values: the
+// epilogue's mean[m] * s[n] then cancels exactly what the product accumulated), c[n] = sum_k w[n][k] beta[k] + b[n].
+__global__ void fold_ln_kernel(const float* __restrict__ w, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ bias, bf16_t* __restrict__ wg,
+                               float* __restrict__ s, float* __restrict__ c, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float* row = w + (long long)n * K;
+    float ss = 0.f, cc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = row[k];
+        const bf16_t g = (bf16_t)(wv * gamma[k]);
+        wg[(long long)n * K + k] = g;
+        ss += (float)g;
+        cc = fmaf(wv, beta[k], cc);
+    }
+    ss = wave_sum(ss);
+    cc = wave_sum(cc);
+    if (lane == 0) {
+        s[n] = ss;
+        c[n] = cc + (bias ? bias[n] : 0.f);
+    }
+}
+
+extern "C" int vitmi_fold_ln(const float* w, const float* gamma, const float* beta, const float* bias, void* w_folded,
+                             float* w_rowsum, float* bias_folded, int N, int K, void* stream) {
+    VITMI_CHECK_ARG(w && gamma && beta && w_folded && w_rowsum && bias_folded, "vitmi_fold_ln: null pointer");
+    VITMI_CHECK_ARG(N > 0 && K > 0, "vitmi_fold_ln: bad shape N=%d K=%d", N, K);
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(VITMI_FAM_OTHER, st, 6.0 * N * K);
+    hipLaunchKernelGGL(fold_ln_kernel, dim3(ceil_div(N, 4)), dim3(256), 0, st, w, gamma, beta, bias, (bf16_t*)w_folded,
+                       w_rowsum, bias_folded, N, K);
+    VITMI_LAUNCH_CHECK("vitmi_fold_ln");
+    return VITMI_OK;
+}
+
 extern "C" int vitmi_row_stats(const void* x, long long ldx, float* mean, float* rstd, int dt, long long rows, int D,
                                float eps, void* stream) {
     VITMI_CHECK_ARG(x && mean && rstd, "vitmi_row_stats: null pointer");

@@ -31,9 +31,11 @@ long long vitmi_colsum_workspace_bytes_impl(long long rows, int cols);
 bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const void* V, long long ldv, const void* C,
                            long long ldc);
 int vitmi_gemm_tn_slabs(int P, int Q, int T);
+int vitmi_gemm_tn_slabs_bound(int P, int Q, int T);
 int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
                        long long ldc, float* slabs, hipStream_t s);
 long long vitmi_gemm_tn_batch_bytes(int n, const int* P, const int* Q, int T);
+long long vitmi_gemm_tn_batch_bytes_bound(int n, const int* P, const int* Q, int T);
 int vitmi_gemm_tn_batch(int n, const int* P, const int* Q, int T, const void* const* U, const long long* ldu,
                         const void* const* V, const long long* ldv, float* const* C, float* partial, hipStream_t s);
 bool vitmi_patch_fast_ok(const void* img, const void* w, const void* out, int W, int p, int D, int E,
@@ -529,7 +531,7 @@ extern "C" int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, con
 extern "C" long long vitmi_patch_embed_bwd_w_workspace_bytes(int dt, int B, int C, int H, int W, int p, int D) {
     if (dt != VITMI_BF16 || p <= 0) return 0;
     const int E = C * p * p, T = B * (H / p) * (W / p);
-    const int ns = vitmi_gemm_tn_slabs(D, E, T);
+    const int ns = vitmi_gemm_tn_slabs_bound(D, E, T);    // independent of the CU reservation in force
     return ns > 1 ? (long long)ns * D * E * (long long)sizeof(float) : 0;
 }
 
@@ -579,7 +581,9 @@ extern "C" int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, 
 
 extern "C" long long vitmi_gemm_wgrad_workspace_bytes(int dt, int P, int Q, int T) {
     if (dt != VITMI_BF16) return 0;
-    const int ns = vitmi_gemm_tn_slabs(P, Q, T);
+    // sized for every CU reservation and tile configuration (vitmi_set_reserved_cus may change between the query
+    // and the call; callers cache the answer per shape)
+    const int ns = vitmi_gemm_tn_slabs_bound(P, Q, T);
     return ns > 1 ? (long long)ns * P * Q * (long long)sizeof(float) : 0;
 }
 
@@ -603,7 +607,7 @@ extern "C" long long vitmi_gemm_wgrad_pair_workspace_bytes(int dt, int T, int P0
     const long long w0 = vitmi_gemm_wgrad_workspace_bytes(dt, P0, Q0, T), w1 = vitmi_gemm_wgrad_workspace_bytes(dt, P1, Q1, T);
     long long b = w0 > w1 ? w0 : w1;
     if (dt == VITMI_BF16) {
-        const long long pair = vitmi_gemm_tn_batch_bytes(2, P, Q, T);
+        const long long pair = vitmi_gemm_tn_batch_bytes_bound(2, P, Q, T);
         if (pair > b) b = pair;
     }
     return b;

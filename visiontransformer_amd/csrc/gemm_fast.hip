@@ -143,7 +143,7 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
                 gelu_both_fast(v[t], v[t], w[t]);
             } else {
                 w[t] = v[t];
-                v[t] = gelu_fast(v[t]);
+                v[t] = EPI == VITMI_EPI_GELU ? gelu_erf_fast(v[t]) : gelu_fast(v[t]);
             }
         }
         if (e.aux) {
@@ -299,8 +299,8 @@ __device__ __forceinline__ void epi_subtile_fast(const FastEpi& e, f32x4 (&acc)[
                 } else {
                     p0[t] = (bf16_t)v[t];
                     p1[t] = (bf16_t)v[8 + t];
-                    v[t] = gelu_fast(v[t]);
-                    v[8 + t] = gelu_fast(v[8 + t]);
+                    v[t] = EPI == VITMI_EPI_GELU ? gelu_erf_fast(v[t]) : gelu_fast(v[t]);
+                    v[8 + t] = EPI == VITMI_EPI_GELU ? gelu_erf_fast(v[8 + t]) : gelu_fast(v[8 + t]);
                 }
             }
             if (e.aux && live) {
@@ -1363,16 +1363,22 @@ int vitmi_reserved_cus() { return g_reserved_cus; }
 
 // persistent blocks of the phased nt kernel: one per CU, rounded down to a multiple of 8 so that a
 // block's tiles stay on its XCD, minus the reserved ones
-static int phased_grid_blocks() {
+// every CU of the current device, rounded down to a multiple of 8: what the workspace-size queries plan with, so
+// that a size asked for under one reservation holds under every other
+static int full_grid_blocks() {
     static int cached[64] = {0};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 256 - g_reserved_cus;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
     int& c = cached[dev & 63];
     if (c == 0) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
         c = cus & ~7;
     }
+    return c;
+}
+static int phased_grid_blocks() {
+    const int c = full_grid_blocks();
     return c - g_reserved_cus > 8 ? c - g_reserved_cus : 8;
 }
 
@@ -1589,6 +1595,21 @@ int vitmi_gemm_tn_slabs(int P, int Q, int T) {
     return s;
 }
 
+// an upper bound of vitmi_gemm_tn_slabs over every CU reservation and every tile configuration (a debug override
+// included): workspace sizes are computed from this, the launch from vitmi_gemm_tn_slabs
+int vitmi_gemm_tn_slabs_bound(int P, int Q, int T) {
+    const int nk = ceil_div(T, TK);
+    int best = 1;
+    for (int bt = 128; bt <= 256; bt += 128) {
+        const int tiles = ceil_div(P, bt) * ceil_div(Q, bt);
+        int s = (bt == 256 ? 1 : 2) * full_grid_blocks() / tiles;
+        if (s > nk) s = nk;
+        if (s > 32) s = 32;
+        if (s > best) best = s;
+    }
+    return best;
+}
+
 template <bool PATCH, int BP, int BQ, int WP, int WQ>
 static int launch_tn_cfg(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
                          long long ldc, float* slabs, int ns, const PatchGeom& pg, hipStream_t s) {
@@ -1751,6 +1772,20 @@ long long vitmi_gemm_tn_batch_bytes(int n, const int* P, const int* Q, int T) {
     TnBatch tb;
     if (!tn_batch_plan(n, P, Q, T, &tb)) return 0;
     return (long long)tb.tiles * tb.spt * TN_SLOT * (long long)sizeof(float);
+}
+
+// an upper bound of vitmi_gemm_tn_batch_bytes over every CU reservation and both states of the batch switch: a tile
+// never gets more main slabs than full chip / tiles, plus one slot for a remainder run
+long long vitmi_gemm_tn_batch_bytes_bound(int n, const int* P, const int* Q, int T) {
+    if (n < 2 || n > 4 || T <= 0 || T % TK) return 0;
+    long long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        if (P[i] <= 0 || Q[i] <= 0 || P[i] % 256 || Q[i] % 256) return 0;
+        tiles += (long long)(P[i] / 256) * (Q[i] / 256);
+    }
+    const long long nmain = full_grid_blocks() / tiles;
+    if (nmain < 1) return 0;
+    return tiles * (nmain + 1) * TN_SLOT * (long long)sizeof(float);
 }
 
 // C[i] (dense [P[i]][Q[i]] fp32) = U[i]^T V[i] over T tokens for i < n; VITMI_ERR_UNSUPPORTED when the shapes do

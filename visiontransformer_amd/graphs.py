@@ -77,15 +77,23 @@ class GraphedInference:
     keep it).
 
     The graph reads the weights from the operands that existed at capture (bf16 compute copies and the weights with
-    LayerNorm folded in).  They are frozen with the graph: after the parameters change (training went on, a
-    load_state_dict) call `refresh()` to capture again."""
+    LayerNorm folded in).  This object keeps those tensors alive, so a replay never reads recycled memory, and it
+    records what the parameters looked like at capture (version counter and address of each, and the count of
+    raw-pointer updates such as FusedAdam.step, which moves no version counter): a call after any of them changed
+    captures again first (`refresh()`; `auto_refresh=False` raises instead)."""
 
-    def __init__(self, model, example_inputs, example_unk_mask=None, warmup=2):
+    def __init__(self, model, example_inputs, example_unk_mask=None, warmup=2, auto_refresh=True):
         self.model = model
         self.x = example_inputs.clone()
         self.unk = example_unk_mask.clone() if example_unk_mask is not None else None
         self.warmup = warmup
+        self.auto_refresh = auto_refresh
         self.refresh()
+
+    def _stamp(self):
+        return (ops.param_epoch(),
+                tuple((p._version, p.data_ptr()) for p in self.model.parameters()),
+                tuple((b._version, b.data_ptr()) for b in self.model.buffers()))
 
     def _run(self):
         return self.model(self.x, unk_mask=self.unk) if self.unk is not None else self.model(self.x)
@@ -104,9 +112,25 @@ class GraphedInference:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = self._run()
+        # the operands the captured launches read: every cached compute copy and folded weight of this model's
+        # parameters (made during the warm-up, outside the graph's memory pool); holding them keeps the caching
+        # allocator from handing their memory to someone else when the caches drop them
+        mine = {id(p) for p in self.model.parameters()}
+        self._held = [ent[2] for key, ent in list(ops._cast_cache.items()) if key[0] in mine]
+        self._held += [ent[2] for key, ent in list(ops._fold_cache.items()) if any(k in mine for k in key)]
+        self._captured = self._stamp()
         self.model.train(was_training)
 
+    def stale(self):
+        """True when a parameter or buffer changed since the capture."""
+        return self._stamp() != self._captured
+
     def __call__(self, inputs, unk_mask=None):
+        if self.stale():
+            if not self.auto_refresh:
+                raise RuntimeError("GraphedInference: the model's parameters changed since the graph was captured; "
+                                   "call refresh()")
+            self.refresh()
         self.x.copy_(inputs, non_blocking=True)
         if self.unk is not None:
             self.unk.copy_(unk_mask, non_blocking=True)

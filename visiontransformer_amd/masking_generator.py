@@ -140,14 +140,9 @@ class JigsawPuzzleMaskedRegion:
         if pub_data is not None:
             self.set_public_data(pub_data)
         elif mask_type == "pbf":
-            try:                        # inside the reference tree: its loader (torchvision ImageFolder) builds the bank
-                from dataloader import public_data
-            except Exception as e:
-                raise ValueError("mask_type 'pbf' needs the public patch bank: pass pub_data=[P, C*p*p, L] (what "
-                                 "dataloader.public_data returns); no importable `dataloader.public_data` was found "
-                                 f"to build it from {pub_data_dir!r} ({type(e).__name__}: {e})") from None
-            self.set_public_data(public_data(root_dir=pub_data_dir, img_size=img_size, patch_size=patch_size,
-                                             channels=channels))
+            raise ValueError("mask_type 'pbf' needs the public patch bank: pass pub_data=[P, C*p*p, L] (the tensor the "
+                             f"reference builds with dataloader.public_data(root_dir={pub_data_dir!r}, ...), "
+                             "dataloader.py:17-37); this package reads no image folders")
 
     def set_public_data(self, pub_data):
         """Keep the bank as the reference holds it (self.pub_data, [P, C*p*p, L]) and as [P, C, H, W] images, the

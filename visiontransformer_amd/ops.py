@@ -159,6 +159,19 @@ _fold_cache = {}
 _infer_fusion = os.environ.get("VITMI_INFER_FUSION", "1") != "0"
 
 
+def set_gelu(mode):
+    """How the bf16 MLP block evaluates nn.GELU() and its derivative (process-wide; fp32 mode always uses erff):
+    "fast" (default) = gelu and gelu' from one fitted sigmoid form in the forward epilogue (errors 3.8e-5 / 9.3e-5
+    against the erf forms, below bf16 rounding), "erf" = the erf form (1.5e-7) with the derivative evaluated from the
+    stored pre-activation in the backward pass.  Returns the previous mode.  Do not switch between a forward pass and
+    its backward pass."""
+    if mode not in ("fast", "erf"):
+        raise ValueError('set_gelu: mode must be "fast" or "erf"')
+    prev = "erf" if lib.vitmi_get_gelu_mode() else "fast"
+    check(lib.vitmi_set_gelu_mode(int(mode == "erf")), "vitmi_set_gelu_mode")
+    return prev
+
+
 def set_inference_fusion(on):
     """Whether forward passes that build no autograd graph take the LayerNorm-folded inference entry points
     (default on; VITMI_INFER_FUSION=0 turns it off at import).  Returns the previous setting."""
@@ -167,8 +180,19 @@ def set_inference_fusion(on):
     return prev
 
 
+_param_epoch = 0
+
+
+def param_epoch():
+    """Counts the events that change parameters behind autograd's back (raw-pointer writes of the fused optimizer
+    kernel, which move no version counter): consumers that captured derived operands compare it."""
+    return _param_epoch
+
+
 def drop_folded():
     """Forget every folded operand (call after parameters were changed without a version bump)."""
+    global _param_epoch
+    _param_epoch += 1
     _fold_cache.clear()
 
 
@@ -179,14 +203,15 @@ def folded_linear(w, ln_w, ln_b, b):
     hit = _fold_cache.get(key)
     if hit is not None and hit[0] == stamp and all(r() is t for r, t in zip(hit[1], parts)):
         return hit[2]
-    with torch.no_grad():
-        w32 = w.detach().float()
-        wg = (w32 * ln_w.detach().float()[None, :]).to(torch.bfloat16).contiguous()
-        s = wg.float().sum(dim=1).contiguous()
-        c = w32 @ ln_b.detach().float()
-        if b is not None:
-            c = c + b.detach().float()
-        c = c.contiguous()
+    _need_gpu(w, ln_w, ln_b, b)
+    n, k = w.shape
+    w32, g32, b32 = (t.detach().float().contiguous() for t in (w, ln_w, ln_b))
+    bias32 = b.detach().float().contiguous() if b is not None else None
+    wg = torch.empty((n, k), dtype=torch.bfloat16, device=w.device)
+    s = torch.empty(n, dtype=torch.float32, device=w.device)
+    c = torch.empty(n, dtype=torch.float32, device=w.device)
+    check(lib.vitmi_fold_ln(_p(w32), _p(g32), _p(b32), _p(bias32), _p(wg), _p(s), _p(c), n, k, _stream()),
+          "vitmi_fold_ln")
 
     def _drop(_ref, key=key):
         _fold_cache.pop(key, None)
@@ -228,6 +253,8 @@ def refresh_pinned_copies(pinned):
 def clear_cast_cache():
     """Drop every cached compute copy (call after parameters were changed behind autograd's back,
     e.g. by the fused optimizer kernel)."""
+    global _param_epoch
+    _param_epoch += 1
     _cast_cache.clear()
     _fold_cache.clear()
 
@@ -1019,7 +1046,7 @@ class FFBlockFn(_BlockFn):
             x2 = cast(x2, cdt)
         whole = ln_w is not None and add_residual and x2.is_contiguous() and drop is None
         if (whole and _infer_fusion and cdt == torch.bfloat16 and _BlockFn.builds_no_graph(ctx)
-                and x2.shape[1] % 8 == 0 and w1.shape[0] % 8 == 0):
+                and x2.shape[1] % 8 == 0 and w1.shape[0] % 8 == 0 and not lib.vitmi_get_gelu_mode()):
             # no autograd graph is being built: LayerNorm folded into the first product, no GELU derivative stored
             wg, s1, c1 = folded_linear(w1, ln_w, ln_b, b1)
             rows, D = x2.shape

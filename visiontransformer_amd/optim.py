@@ -146,9 +146,12 @@ class FusedAdam:
     def _layout(self, device, plist):
         """(records [len, 6] with the per-tensor constants filled in, chunk table) for this set of tensors; rebuilt
         only when the set changes (the state tensors never move, gradients and copies are filled in per step)."""
+        # one entry per SET of tensors: parameters of a group whose step counts differ (one skipped a step) go out
+        # as several launches per step, each with its own cached layout
         key = tuple(id(p) for p in plist)
+        device = (device, key)
         ent = self._layouts.get(device)
-        if ent is None or ent[0] != key:
+        if ent is None:
             recs = np.zeros((len(plist), 6), dtype=np.int64)
             chunks = []
             for ti, p in enumerate(plist):

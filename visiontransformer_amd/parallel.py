@@ -107,6 +107,7 @@ class GradReducer:
         self._stage = bool(self.buckets) and self.buckets[0].flat.is_cuda and not _device_collectives(group)
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self._seen = set()
+        self._dirty = set()         # parameters that accumulated a gradient under no_sync() since the last exchange
         self._next = 0              # first bucket whose collective has not been issued this step
         self._sync = True
         self.reserve_cus = int(reserve_cus)
@@ -143,6 +144,8 @@ class GradReducer:
 
     def _on_grad(self, p):
         if not self._sync:
+            if p.grad is not None:
+                self._dirty.add(p)  # its local sum lives in p.grad and is sent by the next exchange
             return
         if p.grad is None:      # the accumulation node ran with an undefined gradient (a backward pass that hands
             return              # this parameter nothing, e.g. the per-sample-norm pass of DP-SGD): not an arrival
@@ -176,7 +179,7 @@ class GradReducer:
         dst, src = [], []
         for i, p in enumerate(b.params):
             v = b.view(i)
-            if p in self._seen and p.grad is not None:
+            if (p in self._seen or p in self._dirty) and p.grad is not None:
                 if p.grad.data_ptr() != v.data_ptr():
                     dst.append(v)
                     src.append(p.grad)
@@ -189,6 +192,9 @@ class GradReducer:
         """Wait for the exchange; leave averaged gradients in p.grad.  Parameters that took no
         gradient this step (unused in the graph) contribute zeros, like DDP with
         find_unused_parameters=True."""
+        if not self._sync:
+            raise RuntimeError("GradReducer.finish() inside no_sync(): leave the context first (the backward passes "
+                               "inside it only accumulate locally)")
         scale = 1.0 / self.world if self.average else 1.0
         for b in self.buckets[self._next:]:     # incomplete buckets, in the order every rank uses
             self._launch(b)
@@ -219,6 +225,7 @@ class GradReducer:
             b.work = None
         self._next = 0
         self._seen.clear()
+        self._dirty.clear()
 
     def remove(self):
         for h in self._handles:
