@@ -68,7 +68,9 @@ def test_phased_nt_gemm_forward_epilogues_at_bench_shapes(ops, M, N, K):
         h2, gp = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_GELU_D, want_aux=True)
         pr = (pre + b).requires_grad_(True)
         vit_oracle.gelu_erf(pr).sum().backward()
-        assert torch.equal(h2, h) and rel_err(deriv(gp), pr.grad) < 1e-2
+        # <GELU> evaluates the erf form, <GELU_D> the fitted sigmoid form (3.8e-5 apart before rounding): equal up to
+        # a bf16 unit in the last place
+        assert rel_err(h2, h) < 8e-3 and rel_err(deriv(gp), pr.grad) < 1e-2
     if N == 768 and K == 768:
         y32, _ = ops.linear_fwd(xd, wd, bd, out_dtype=torch.float32)
         assert rel_err(y32, pre + b) < 2e-3

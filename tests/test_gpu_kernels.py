@@ -381,7 +381,9 @@ def test_fast_nt_gemm_all_epilogues(ops, M, N, K):
     h2, gp = ops.linear_fwd(xd, wd, bd, epi=ops.EPI_GELU_D, want_aux=True)
     pr = pre.clone().requires_grad_(True)
     vit_oracle.gelu_erf(pr).sum().backward()
-    assert torch.equal(h2, h) and rel_err(deriv(gp), pr.grad) < 1e-2
+    # <GELU> evaluates the erf form, <GELU_D> the fitted sigmoid form (3.8e-5 apart before rounding): equal up to
+    # bf16 units in the last place (3.9e-3 of the largest value each)
+    assert rel_err(h2, h) < 8e-3 and rel_err(deriv(gp), pr.grad) < 1e-2
     auxh = aux.float().half().view(torch.bfloat16)                 # the pair keeps its aux as IEEE half bits
     dm = ops.linear_bwd_x(dy.to(DEV, dtype), wd, epi=ops.EPI_MULAUX, aux=auxh, w_t=wt)
     assert rel_err(dm, (q(dy, dtype) @ q(w, dtype)) * deriv(auxh).cpu()) < 1e-2

@@ -29,7 +29,11 @@ def per_kernel(root, counter):
 
 fetch, nf = per_kernel(sys.argv[1], "FETCH_SIZE")
 write, nw = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"_about": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `{sys.argv[4]}`, MI355X. Counter unit "
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import kernel_source_hash  # noqa: E402  (bench.py refuses a summary collected on other kernel sources)
+
+out = {"kernel_source_hash": kernel_source_hash(),
+       "_about": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `{sys.argv[4]}`, MI355X. Counter unit "
                  "is KB per dispatch; bytes = KB*1024; FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B).",
        "kernels": {}}
 for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0.0))):

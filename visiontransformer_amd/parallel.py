@@ -113,6 +113,11 @@ class GradReducer:
         self.reserve_cus = int(reserve_cus)
         if self.reserve_cus:
             self._reserve(self.reserve_cus)
+        # timeline of the exchange (device tensors only): events of the last finished step, see timeline()
+        self.record_timeline = False
+        self._ev_bwd_start = None
+        self._ev_issue = {}
+        self._last = None
 
     @staticmethod
     def _reserve(k):
@@ -165,7 +170,32 @@ class GradReducer:
             self._launch(self.buckets[self._next])
             self._next += 1
 
+    def mark_backward_start(self):
+        """Call right before loss.backward() when record_timeline is on: the origin of the step's timeline."""
+        if self.record_timeline and self.buckets and self.buckets[0].flat.is_cuda:
+            self._ev_bwd_start = torch.cuda.Event(enable_timing=True)
+            self._ev_bwd_start.record()
+
+    def timeline(self):
+        """Of the last step finished with record_timeline on (synchronises the device): milliseconds from
+        mark_backward_start() to the end of backward (`backward_ms`), from the end of backward until every bucket has
+        been reduced and unpacked on the compute stream (`exposed_comm_ms`: what the step pays for the exchange beyond
+        the backward pass it hides under), and per bucket when its collective was issued and when the compute stream
+        was past its wait (`buckets`: [issue_ms, done_ms] from the same origin, in bucket order)."""
+        if self._last is None:
+            return None
+        start, bwd_end, comm_done, issue, done = self._last
+        torch.cuda.synchronize()
+        t0 = start if start is not None else bwd_end
+        return {"backward_ms": t0.elapsed_time(bwd_end) if start is not None else None,
+                "exposed_comm_ms": bwd_end.elapsed_time(comm_done),
+                "buckets": [[round(t0.elapsed_time(i), 3), round(t0.elapsed_time(d), 3)] for i, d in zip(issue, done)]}
+
     def _launch(self, b):
+        if self.record_timeline and b.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._ev_issue[id(b)] = ev
         self._pack(b)
         if self._stage:             # no device collectives on this backend: reduce a host copy
             b.host = b.flat.float().cpu() if b.flat.dtype != torch.float32 else b.flat.cpu()
@@ -196,11 +226,20 @@ class GradReducer:
             raise RuntimeError("GradReducer.finish() inside no_sync(): leave the context first (the backward passes "
                                "inside it only accumulate locally)")
         scale = 1.0 / self.world if self.average else 1.0
+        rec = self.record_timeline and bool(self.buckets) and self.buckets[0].flat.is_cuda
+        if rec:
+            bwd_end = torch.cuda.Event(enable_timing=True)
+            bwd_end.record()
+            done = []
         for b in self.buckets[self._next:]:     # incomplete buckets, in the order every rank uses
             self._launch(b)
         self._next = len(self.buckets)
         for b in self.buckets:
             b.work.wait()
+            if rec:
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                done.append(ev)
             if b.host is not None:
                 b.flat.copy_(b.host)
                 b.host = None
@@ -223,6 +262,11 @@ class GradReducer:
             b.pending = len(b.params)
             b.ready = False
             b.work = None
+        if rec:
+            comm_done = torch.cuda.Event(enable_timing=True)
+            comm_done.record()
+            self._last = (self._ev_bwd_start, bwd_end, comm_done, [self._ev_issue[id(b)] for b in self.buckets], done)
+            self._ev_issue = {}
         self._next = 0
         self._seen.clear()
         self._dirty.clear()
