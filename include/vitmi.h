@@ -395,14 +395,26 @@ int vitmi_ff_block_infer(int rows, int D, int M, const void* x, float eps, const
  *   vitmi_seg_colsum_sqnorm     || sum_t x[t,:] ||^2            (biases: x = dy)
  *   vitmi_seg_layernorm_sqnorm  || sum_t dy*xhat ||^2 + || sum_t dy ||^2   (LayerNorm weight and bias; dy dense [rows,D])
  *   vitmi_seg_sqnorm            sum_t || x[t,:] ||^2            (positional table, class token: x = dx)
- * Reductions run in a fixed order; each sqnorm entry has a single writer per launch. */
+ * Reductions run in a fixed order; each sqnorm entry has a single writer per launch.
+ * The two column-sum routines can also leave the per-image sums themselves (`sums` [segments, cols] fp32, NULL = not
+ * wanted).  With the clipping factors c_i = min(1, C / ||g_i||) known, the clipped gradient sum_i c_i g_i then needs no
+ * second pass over the network (the upstream gradient of image i in a backward pass of sum_i c_i loss_i is c_i times
+ * its value in the norm pass):
+ *   vitmi_seg_combine           out[c] = sum_i coef[i] x[i][c]  (vector parameters: x = the per-image sums)
+ *   vitmi_seg_scale_rows        out[t,:] = x[t,:] * coef[t / seg]: one operand of a weight-gradient product, so that
+ *                               vitmi_gemm_wgrad(dy, coef-scaled x) = sum_i c_i dy_i^T x_i */
 long long vitmi_wgrad_sqnorm_workspace_bytes(int dt, int P, int Q, int T, int seg);
 int vitmi_wgrad_sqnorm(int dt, int P, int Q, int T, int seg, const void* U, long long ldu, const void* V, long long ldv,
                        float* sqnorm, void* workspace, void* stream);
 int vitmi_seg_colsum_sqnorm(const void* x, int dt, long long rows, int cols, long long ld, int seg, float* sqnorm,
-                            void* stream);
+                            float* sums, void* stream);
 int vitmi_seg_layernorm_sqnorm(const void* dy, const void* x, long long ldx, const float* mean, const float* rstd, int dt,
-                               long long rows, int D, int seg, float* sqnorm, void* stream);
+                               long long rows, int D, int seg, float* sqnorm, float* sums_beta, float* sums_gamma,
+                               void* stream);
+int vitmi_seg_combine(const void* x, int dt, int n, long long cols, long long ld, const float* coef, float* out,
+                      void* stream);
+int vitmi_seg_scale_rows(const void* x, int dt, long long rows, int cols, long long ld, int seg, const float* coef,
+                         void* out, long long ldo, void* stream);
 int vitmi_seg_sqnorm(const void* x, int dt, long long rows, int cols, long long ld, int seg, float* sqnorm, void* stream);
 
 /* mean over tokens: out[b,:] = mean_i x[b,i,:]  (pool == 'mean', mymodel/ViT.py:164) and its

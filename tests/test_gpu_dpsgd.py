@@ -35,9 +35,12 @@ def oracle_per_sample(loss_and_grads, params, x, y, heads, **kw):
     return torch.stack(norms), {k: v / x.shape[0] for k, v in total.items()}
 
 
+@pytest.mark.parametrize("reuse", [True, False], ids=["replay", "second_backward"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("geom", list(GEOMETRIES))
-def test_norms_and_clipped_sum_against_oracle(geom, dtype):
+def test_norms_and_clipped_sum_against_oracle(geom, dtype, reuse):
+    """reuse: the clipped sum from the tensors the norm pass kept (ops.clipped_replay; no second input-gradient
+    chain) or from an ordinary second backward of sum_i c_i loss_i -- the same bars for both."""
     from visiontransformer_amd import ViT, dpsgd
     kw = GEOMETRIES[geom]
     B = 5
@@ -52,10 +55,13 @@ def test_norms_and_clipped_sum_against_oracle(geom, dtype):
     m = ViT.VIT(**kw)
     m.load_state_dict(params)
     m = m.to(DEV).set_compute_dtype(dtype).train()
-    loss, norms = dpsgd.clipped_noised_gradients(m, x.to(DEV), y.to(DEV), l2_norm_clip=CLIP, noise_multiplier=0.0)
+    loss, norms = dpsgd.clipped_noised_gradients(m, x.to(DEV), y.to(DEV), l2_norm_clip=CLIP, noise_multiplier=0.0,
+                                                 reuse_norm_pass=reuse)
     assert rel_err(norms, ref_norms) < TOL[dtype]
     worst = max((rel_err(p.grad, ref_grads[k]), k) for k, p in m.named_parameters())
     assert worst[0] < TOL[dtype], worst                   # measured worst: 2.2e-6 fp32, 1.1e-2 bf16
+    if not reuse:
+        return
     # the literal schedule (B passes of one image) gives the same gradient
     m2 = ViT.VIT(**kw)
     m2.load_state_dict(params)
@@ -66,8 +72,9 @@ def test_norms_and_clipped_sum_against_oracle(geom, dtype):
     assert worst[0] < TOL[dtype], worst
 
 
+@pytest.mark.parametrize("reuse", [True, False], ids=["replay", "second_backward"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_timm_style_model_norms(dtype):
+def test_timm_style_model_norms(dtype, reuse):
     """The model DPSGD.py:151 builds (qkv bias, final norm) at a small geometry."""
     from test_gpu_timm_vit import make
     from visiontransformer_amd import dpsgd
@@ -78,15 +85,13 @@ def test_timm_style_model_norms(dtype):
     ref_norms, ref_grads = oracle_per_sample(timm_vit_oracle.loss_and_grads, params, x, y, args["num_heads"])
     m.train()
     _, norms = dpsgd.clipped_noised_gradients(m, x.to(DEV), y.to(DEV), l2_norm_clip=CLIP, noise_multiplier=0.0,
-                                              unk_mask=None)
+                                              unk_mask=None, reuse_norm_pass=reuse)
     assert rel_err(norms, ref_norms) < TOL[dtype]
-    # Every tensor at the 1e-4 / 2e-2 bar but the LayerNorm weights in bf16: their clipped gradient is a sum over
-    # tokens of dy * xhat with heavy cancellation (max|ref| 1.9e-3 where the summands reach 1e-1), and with max|a-b| /
-    # max|b| as the measure one element of blocks.0.norm2.weight sits at 2.2e-2 (rms ratio 1.3e-2).  They get 3e-2
-    # on the maximum and the 2e-2 bar on the rms ratio.
+    # every tensor at the 1e-4 / 2e-2 bar, by the maximum and by the rms ratio (measured worst in bf16: the LayerNorm
+    # weights, sums over tokens of dy * xhat with heavy cancellation, 1.3e-2 with the replay and 1.5e-2 with the second
+    # backward)
     for k, p in m.named_parameters():
-        loose = dtype == torch.bfloat16 and k.endswith(("norm1.weight", "norm2.weight"))
-        assert rel_err(p.grad, ref_grads[k]) < (3e-2 if loose else TOL[dtype]), k
+        assert rel_err(p.grad, ref_grads[k]) < TOL[dtype], k
         d = (p.grad.detach().double().cpu() - ref_grads[k].double())
         assert (d.pow(2).mean().sqrt() / ref_grads[k].double().pow(2).mean().sqrt()) < TOL[dtype], k
 

@@ -78,8 +78,10 @@ SIGNATURES = {
     "vitmi_transpose_cast_multi": (I, [P, P, I, L, P]),
     "vitmi_wgrad_sqnorm_workspace_bytes": (L, [I, I, I, I, I]),
     "vitmi_wgrad_sqnorm": (I, [I, I, I, I, I, P, L, P, L, P, P, P]),
-    "vitmi_seg_colsum_sqnorm": (I, [P, I, L, I, L, I, P, P]),
-    "vitmi_seg_layernorm_sqnorm": (I, [P, P, L, P, P, I, L, I, I, P, P]),
+    "vitmi_seg_colsum_sqnorm": (I, [P, I, L, I, L, I, P, P, P]),
+    "vitmi_seg_layernorm_sqnorm": (I, [P, P, L, P, P, I, L, I, I, P, P, P, P]),
+    "vitmi_seg_combine": (I, [P, I, I, L, L, P, P, P]),
+    "vitmi_seg_scale_rows": (I, [P, I, L, I, L, I, P, P, L, P]),
     "vitmi_seg_sqnorm": (I, [P, I, L, I, L, I, P, P]),
     "vitmi_seq_ord": (I, [P, I, P, I, L, P]),
     "vitmi_jigsaw_gather": (I, [P, P, I, I, I, I, I, I, P, P, I, P, P, P]),

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void dense_sq_accum_kernel(const float* __rest
 // sqnorm[s] += || sum_{t in segment s} x[t, :] ||^2
 template <typename T>
 __global__ __launch_bounds__(256) void seg_colsum_sq_kernel(const T* __restrict__ x, long long ld, long long rows, int cols,
-                                                           int seg, float* __restrict__ sqnorm) {
+                                                           int seg, float* __restrict__ sqnorm, float* __restrict__ sums) {
     __shared__ float red[4];
     const long long r0 = (long long)blockIdx.x * seg;
     const long long r1 = r0 + seg < rows ? r0 + seg : rows;
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void seg_colsum_sq_kernel(const T* __restrict_
     for (int c = threadIdx.x; c < cols; c += 256) {
         float s = 0.f;
         for (long long t = r0; t < r1; ++t) s += to_f32(x[t * ld + c]);
+        if (sums) sums[(long long)blockIdx.x * cols + c] = s;
         acc = fmaf(s, s, acc);
     }
     acc = block_sum_256(acc, red);
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(256) void seg_colsum_sq_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void seg_ln_sq_kernel(const T* __restrict__ dy, const T* __restrict__ x, long long ldx,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                       long long rows, int D, int seg, float* __restrict__ sqnorm) {
+                                                       long long rows, int D, int seg, float* __restrict__ sqnorm,
+                                                       float* __restrict__ sums_b, float* __restrict__ sums_g) {
     __shared__ float red[4];
     const long long r0 = (long long)blockIdx.x * seg;
     const long long r1 = r0 + seg < rows ? r0 + seg : rows;
@@ -73,6 +75,10 @@ __global__ __launch_bounds__(256) void seg_ln_sq_kernel(const T* __restrict__ dy
             const float d = to_f32(dy[t * D + c]);
             sg = fmaf(d, (to_f32(x[t * ldx + c]) - mean[t]) * rstd[t], sg);
             sb += d;
+        }
+        if (sums_b) {
+            sums_b[(long long)blockIdx.x * D + c] = sb;
+            sums_g[(long long)blockIdx.x * D + c] = sg;
         }
         acc = fmaf(sg, sg, fmaf(sb, sb, acc));
     }
@@ -108,7 +114,9 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_colsum_sq_wide_kernel(cons
                                                                             long long ld, long long ldx,
                                                                             const float* __restrict__ mean,
                                                                             const float* __restrict__ rstd, long long rows,
-                                                                            int cols, int seg, float* __restrict__ sqnorm) {
+                                                                            int cols, int seg, float* __restrict__ sqnorm,
+                                                                            float* __restrict__ sums_b,
+                                                                            float* __restrict__ sums_g) {
     constexpr int VEC = SegVec<T>::N;
     typedef SegVec<T> __attribute__((aligned(16))) VT;
     __shared__ float part[SEG_WAVES][64 * VEC * (LN ? 2 : 1)];
@@ -171,6 +179,10 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_colsum_sq_wide_kernel(cons
                     b += part[r * P + wave][lane * VEC + j];
                     if (LN) g += part[r * P + wave][64 * VEC + lane * VEC + j];
                 }
+                if (sums_b) {                             // the segment's column sums themselves, for a later weighted sum
+                    sums_b[(long long)blockIdx.x * cols + c + j] = b;
+                    if (LN) sums_g[(long long)blockIdx.x * cols + c + j] = g;
+                }
                 total = fmaf(b, b, total);
                 if (LN) total = fmaf(g, g, total);
             }
@@ -184,6 +196,42 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void seg_colsum_sq_wide_kernel(cons
         for (int w = 0; w < SEG_WAVES; ++w) t += red[w];
         sqnorm[blockIdx.x] += t;
     }
+}
+
+// out[t][:] = x[t][:] * coef[t / seg]: one operand of a weight-gradient product with every image's rows scaled by
+// the image's clipping factor (sum_i c_i dY_i^T X_i = dY^T (c X))
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void seg_scale_rows_kernel(const T* __restrict__ x, long long ld, long long rows, int cols,
+                                                            int seg, const float* __restrict__ coef, T* __restrict__ out,
+                                                            long long ldo) {
+    const int cpr = cols / VEC;                            // vectors per row
+    const long long n = rows * cpr;
+    struct __attribute__((aligned(sizeof(T) * VEC))) V { T v[VEC]; };
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long t = i / cpr;
+        const int c = (int)(i - t * cpr) * VEC;
+        const float k = coef[t / seg];
+        V a = *reinterpret_cast<const V*>(x + t * ld + c);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a.v[j] = from_f32<T>(to_f32(a.v[j]) * k);
+        *reinterpret_cast<V*>(out + t * ldo + c) = a;
+    }
+}
+
+// out[c] = sum_i coef[i] * x[i][c], i < n in order: a vector parameter's clipped gradient from the per-image sums
+template <typename T>
+__global__ __launch_bounds__(256) void seg_combine_kernel(const T* __restrict__ x, long long ld, int n, long long cols,
+                                                         const float* __restrict__ coef, float* __restrict__ out) {
+    const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float a0 = 0.f, a1 = 0.f;
+    int i = 0;
+    for (; i + 1 < n; i += 2) {
+        a0 = fmaf(coef[i], to_f32(x[(long long)i * ld + c]), a0);
+        a1 = fmaf(coef[i + 1], to_f32(x[(long long)(i + 1) * ld + c]), a1);
+    }
+    if (i < n) a0 = fmaf(coef[i], to_f32(x[(long long)i * ld + c]), a0);
+    out[c] = a0 + a1;
 }
 
 inline bool wide_ok(const void* p, long long ld, int cols, int dt) {
@@ -244,7 +292,7 @@ extern "C" int vitmi_wgrad_sqnorm(int dt, int P, int Q, int T, int seg, const vo
     VITMI_CHECK_ARG(rows > 0 && cols > 0 && seg > 0 && ld >= cols, who ": bad shape")
 
 extern "C" int vitmi_seg_colsum_sqnorm(const void* x, int dt, long long rows, int cols, long long ld, int seg,
-                                       float* sqnorm, void* stream) {
+                                       float* sqnorm, float* sums, void* stream) {
     SEG_ARGS_OK("vitmi_seg_colsum_sqnorm");
     hipStream_t s = as_stream(stream);
     const int nseg = (int)((rows + seg - 1) / seg);
@@ -252,17 +300,17 @@ extern "C" int vitmi_seg_colsum_sqnorm(const void* x, int dt, long long rows, in
         if (dt == VITMI_F32)
             hipLaunchKernelGGL((seg_colsum_sq_wide_kernel<float, false>), dim3(nseg), dim3(64 * SEG_WAVES), 0, s,
                                (const float*)x, (const float*)nullptr, ld, 0ll, (const float*)nullptr, (const float*)nullptr,
-                               rows, cols, seg, sqnorm);
+                               rows, cols, seg, sqnorm, sums, (float*)nullptr);
         else
             hipLaunchKernelGGL((seg_colsum_sq_wide_kernel<bf16_t, false>), dim3(nseg), dim3(64 * SEG_WAVES), 0, s,
                                (const bf16_t*)x, (const bf16_t*)nullptr, ld, 0ll, (const float*)nullptr,
-                               (const float*)nullptr, rows, cols, seg, sqnorm);
+                               (const float*)nullptr, rows, cols, seg, sqnorm, sums, (float*)nullptr);
     } else if (dt == VITMI_F32)
         hipLaunchKernelGGL((seg_colsum_sq_kernel<float>), dim3(nseg), dim3(256), 0, s, (const float*)x, ld, rows, cols, seg,
-                           sqnorm);
+                           sqnorm, sums);
     else
         hipLaunchKernelGGL((seg_colsum_sq_kernel<bf16_t>), dim3(nseg), dim3(256), 0, s, (const bf16_t*)x, ld, rows, cols,
-                           seg, sqnorm);
+                           seg, sqnorm, sums);
     VITMI_LAUNCH_CHECK("vitmi_seg_colsum_sqnorm");
     return VITMI_OK;
 }
@@ -283,8 +331,9 @@ extern "C" int vitmi_seg_sqnorm(const void* x, int dt, long long rows, int cols,
 
 extern "C" int vitmi_seg_layernorm_sqnorm(const void* dy, const void* x, long long ldx, const float* mean,
                                           const float* rstd, int dt, long long rows, int D, int seg, float* sqnorm,
-                                          void* stream) {
+                                          float* sums_beta, float* sums_gamma, void* stream) {
     VITMI_CHECK_ARG(dy && x && mean && rstd && sqnorm, "vitmi_seg_layernorm_sqnorm: null pointer");
+    VITMI_CHECK_ARG(!sums_beta == !sums_gamma, "vitmi_seg_layernorm_sqnorm: both sums or neither");
     VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_seg_layernorm_sqnorm: bad dtype %d", dt);
     VITMI_CHECK_ARG(rows > 0 && D > 0 && seg > 0 && ldx >= D, "vitmi_seg_layernorm_sqnorm: bad shape");
     hipStream_t s = as_stream(stream);
@@ -292,16 +341,65 @@ extern "C" int vitmi_seg_layernorm_sqnorm(const void* dy, const void* x, long lo
     if (wide_ok(dy, D, D, dt) && wide_ok(x, ldx, D, dt) && seg >= 2 * SEG_WAVES) {
         if (dt == VITMI_F32)
             hipLaunchKernelGGL((seg_colsum_sq_wide_kernel<float, true>), dim3(nseg), dim3(64 * SEG_WAVES), 0, s,
-                               (const float*)dy, (const float*)x, (long long)D, ldx, mean, rstd, rows, D, seg, sqnorm);
+                               (const float*)dy, (const float*)x, (long long)D, ldx, mean, rstd, rows, D, seg, sqnorm,
+                               sums_beta, sums_gamma);
         else
             hipLaunchKernelGGL((seg_colsum_sq_wide_kernel<bf16_t, true>), dim3(nseg), dim3(64 * SEG_WAVES), 0, s,
-                               (const bf16_t*)dy, (const bf16_t*)x, (long long)D, ldx, mean, rstd, rows, D, seg, sqnorm);
+                               (const bf16_t*)dy, (const bf16_t*)x, (long long)D, ldx, mean, rstd, rows, D, seg, sqnorm,
+                               sums_beta, sums_gamma);
     } else if (dt == VITMI_F32)
         hipLaunchKernelGGL((seg_ln_sq_kernel<float>), dim3(nseg), dim3(256), 0, s, (const float*)dy, (const float*)x, ldx,
-                           mean, rstd, rows, D, seg, sqnorm);
+                           mean, rstd, rows, D, seg, sqnorm, sums_beta, sums_gamma);
     else
         hipLaunchKernelGGL((seg_ln_sq_kernel<bf16_t>), dim3(nseg), dim3(256), 0, s, (const bf16_t*)dy, (const bf16_t*)x, ldx,
-                           mean, rstd, rows, D, seg, sqnorm);
+                           mean, rstd, rows, D, seg, sqnorm, sums_beta, sums_gamma);
     VITMI_LAUNCH_CHECK("vitmi_seg_layernorm_sqnorm");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_seg_scale_rows(const void* x, int dt, long long rows, int cols, long long ld, int seg,
+                                    const float* coef, void* out, long long ldo, void* stream) {
+    VITMI_CHECK_ARG(x && coef && out, "vitmi_seg_scale_rows: null pointer");
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_seg_scale_rows: bad dtype %d", dt);
+    VITMI_CHECK_ARG(rows > 0 && cols > 0 && seg > 0 && ld >= cols && ldo >= cols, "vitmi_seg_scale_rows: bad shape");
+    hipStream_t s = as_stream(stream);
+    const int vec = dt == VITMI_F32 ? 4 : 8;
+    const bool wide = wide_ok(x, ld, cols, dt) && wide_ok(out, ldo, cols, dt);
+    const long long n = rows * (wide ? cols / vec : cols);
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
+    ProfScope prof(VITMI_FAM_OTHER, s, 2.0 * rows * cols * (dt == VITMI_F32 ? 4 : 2));
+    if (dt == VITMI_F32) {
+        if (wide)
+            hipLaunchKernelGGL((seg_scale_rows_kernel<float, 4>), dim3(blocks), dim3(256), 0, s, (const float*)x, ld, rows, cols,
+                               seg, coef, (float*)out, ldo);
+        else
+            hipLaunchKernelGGL((seg_scale_rows_kernel<float, 1>), dim3(blocks), dim3(256), 0, s, (const float*)x, ld, rows, cols,
+                               seg, coef, (float*)out, ldo);
+    } else {
+        if (wide)
+            hipLaunchKernelGGL((seg_scale_rows_kernel<bf16_t, 8>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, ld, rows,
+                               cols, seg, coef, (bf16_t*)out, ldo);
+        else
+            hipLaunchKernelGGL((seg_scale_rows_kernel<bf16_t, 1>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, ld, rows,
+                               cols, seg, coef, (bf16_t*)out, ldo);
+    }
+    VITMI_LAUNCH_CHECK("vitmi_seg_scale_rows");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_seg_combine(const void* x, int dt, int n, long long cols, long long ld, const float* coef, float* out,
+                                 void* stream) {
+    VITMI_CHECK_ARG(x && coef && out, "vitmi_seg_combine: null pointer");
+    VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "vitmi_seg_combine: bad dtype %d", dt);
+    VITMI_CHECK_ARG(n > 0 && cols > 0 && ld >= cols, "vitmi_seg_combine: bad shape");
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_OTHER, s, 1.0 * n * cols * (dt == VITMI_F32 ? 4 : 2));
+    const unsigned blocks = (unsigned)((cols + 255) / 256);
+    if (dt == VITMI_F32)
+        hipLaunchKernelGGL((seg_combine_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)x, ld, n, cols, coef, out);
+    else
+        hipLaunchKernelGGL((seg_combine_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, ld, n, cols, coef,
+                           out);
+    VITMI_LAUNCH_CHECK("vitmi_seg_combine");
     return VITMI_OK;
 }

@@ -541,11 +541,17 @@ def patch_weighted_mean(x, p, weight):
 # of ||g_i||^2 to .sq[i] and hands autograd no parameter gradients; input gradients flow as usual
 # ---------------------------------------------------------------------------------------------
 _PS = None
+_PS2 = None
 
 
 class per_sample_norms:
-    def __init__(self, batch, device):
+    """keep=True: every node also keeps what `clipped_replay` needs to form sum_i c_i g_i afterwards without a second
+    pass over the network (the upstream gradients of its parameter products and the per-image sums of its vector
+    parameters)."""
+
+    def __init__(self, batch, device, keep=False):
         self.batch = int(batch)
+        self.keep = bool(keep)
         self.sq = torch.zeros(self.batch, dtype=torch.float32, device=device)
 
     def __enter__(self):
@@ -566,6 +572,62 @@ class per_sample_norms:
         return rows // self.batch
 
 
+class clipped_replay:
+    """A backward pass inside hands every parameter sum_i coef[i] g_i, formed from what the norm pass
+    (`per_sample_norms(keep=True)` over the same graph, retain_graph=True) kept: the upstream gradient of image i under
+    the loss sum_i coef[i] loss_i is coef[i] times its value under sum_i loss_i, so the input-gradient chain is not run
+    again -- each node scales the rows of one operand of its weight-gradient products by the image's factor and
+    combines the per-image sums of its vector parameters.  Gradients with respect to the nodes' inputs are returned as
+    zeros (stride-0 placeholders): only parameter gradients are meaningful after such a pass."""
+
+    def __init__(self, coef):
+        self.coef = coef.detach().to(torch.float32).contiguous()
+
+    def __enter__(self):
+        global _PS2
+        if _PS2 is not None or _PS is not None:
+            raise RuntimeError("clipped_replay does not nest")
+        _PS2 = self
+        return self
+
+    def __exit__(self, *exc):
+        global _PS2
+        _PS2 = None
+        return False
+
+
+def _kept(ctx):
+    k = getattr(ctx, "kept", None)
+    if k is None:
+        raise RuntimeError("clipped_replay: this node kept nothing -- run per_sample_norms(keep=True) over the same "
+                           "graph first (retain_graph=True)")
+    ctx.kept = None             # one replay per norm pass: the kept tensors are released here
+    return k
+
+
+def _no_grad_like(shape, dtype, device):
+    """A zero gradient of the given shape that occupies one element (for inputs whose gradient a replay does not form)."""
+    return torch.zeros((), dtype=dtype, device=device).expand(shape)
+
+
+def seg_scale_rows(x2, coef, seg):
+    """x2[t, :] * coef[t // seg] as a new tensor."""
+    rows, cols = x2.shape
+    out = torch.empty((rows, cols), dtype=x2.dtype, device=x2.device)
+    check(lib.vitmi_seg_scale_rows(_p(x2), _dt(x2), rows, cols, x2.stride(0), int(seg), _p(coef), _p(out), cols, _stream()),
+          "vitmi_seg_scale_rows")
+    return out
+
+
+def seg_combine(sums, coef):
+    """sum_i coef[i] * sums[i, :] (fp32 [cols])."""
+    n, cols = sums.shape
+    out = torch.empty(cols, dtype=torch.float32, device=sums.device)
+    check(lib.vitmi_seg_combine(_p(sums), _dt(sums), n, cols, sums.stride(0), _p(coef), _p(out), _stream()),
+          "vitmi_seg_combine")
+    return out
+
+
 def ps_weight(ps, dy2, x2):
     """|| dy_i^T x_i ||_F^2 of y = x W^T, per sample."""
     rows, P = dy2.shape
@@ -584,17 +646,24 @@ def ps_weight(ps, dy2, x2):
                                  _stream()), "vitmi_wgrad_sqnorm")
 
 
-def ps_bias(ps, dy2):
+def ps_bias(ps, dy2, want_sums=False):
+    """Adds || sum_t dy_i ||^2; with want_sums returns the per-image column sums [B, cols] (fp32)."""
     rows, cols = dy2.shape
-    check(lib.vitmi_seg_colsum_sqnorm(_p(dy2), _dt(dy2), rows, cols, dy2.stride(0), ps.seg(rows), _p(ps.sq), _stream()),
-          "vitmi_seg_colsum_sqnorm")
+    sums = torch.empty((ps.batch, cols), dtype=torch.float32, device=dy2.device) if want_sums else None
+    check(lib.vitmi_seg_colsum_sqnorm(_p(dy2), _dt(dy2), rows, cols, dy2.stride(0), ps.seg(rows), _p(ps.sq), _p(sums),
+                                      _stream()), "vitmi_seg_colsum_sqnorm")
+    return sums
 
 
-def ps_layernorm(ps, dy2, x2, mean, rstd):
+def ps_layernorm(ps, dy2, x2, mean, rstd, want_sums=False):
+    """LayerNorm weight and bias; with want_sums returns (per-image sums of dy, per-image sums of dy * xhat)."""
     rows, D = x2.shape
     dy2 = dy2.contiguous()
+    sb = torch.empty((ps.batch, D), dtype=torch.float32, device=dy2.device) if want_sums else None
+    sg = torch.empty((ps.batch, D), dtype=torch.float32, device=dy2.device) if want_sums else None
     check(lib.vitmi_seg_layernorm_sqnorm(_p(dy2), _p(x2), x2.stride(0), _p(mean), _p(rstd), _dt(x2), rows, D, ps.seg(rows),
-                                         _p(ps.sq), _stream()), "vitmi_seg_layernorm_sqnorm")
+                                         _p(ps.sq), _p(sb), _p(sg), _stream()), "vitmi_seg_layernorm_sqnorm")
+    return (sb, sg) if want_sums else None
 
 
 def ps_rows(ps, x2, cols, ld, rows, seg):
@@ -704,9 +773,16 @@ class PatchEmbedFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         B, C, H, W, p, per = ctx.geom
         D = weight.shape[0]
+        rp = _PS2
+        if rp is not None:                  # dW = sum_i c_i dy_i^T P_i: scale the rows of the kept dy, then as usual
+            dy = seg_scale_rows(_kept(ctx).view(B * per, D), rp.coef, per).view(B, per, D)
+            if ctx.needs_input_grad[0]:
+                raise NotImplementedError("clipped replay with a gradient into the images")
         dy = dy.contiguous()
         ps = _PS
         if ps is not None:
+            if ps.keep:
+                ctx.kept = dy
             if ctx.in_place:
                 patches = torch.empty((B * per, C * p * p), dtype=ctx.cdt, device=x.device)
                 check(lib.vitmi_patchify(_p(x), _dt(x), _p(patches), _dt(ctx.cdt), B, C, H, W, p, _stream()),
@@ -759,10 +835,15 @@ class TokensFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dx):
-        dx = dx.contiguous()
+        rp = _PS2
         B, N, D = dx.shape
+        if rp is not None:
+            dx = seg_scale_rows(_kept(ctx).view(B, N * D), rp.coef, 1).view(B, N, D)
+        dx = dx.contiguous()
         ps = _PS
         if ps is not None:
+            if ps.keep:
+                ctx.kept = dx
             ps_rows(ps, dx, D, N * D, B, 1)                             # class token: row 0 of every image
             if ctx.pe_shape is not None:
                 if ctx.seq_ord is not None:
@@ -797,9 +878,16 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, g, mean, rstd = ctx.saved_tensors
+        rp = _PS2
+        if rp is not None:                  # stand-alone LayerNorm (the head's): scale dy's rows, then the usual sums
+            dys = seg_scale_rows(_kept(ctx), rp.coef, x2.shape[0] // rp.coef.numel())
+            _, dg, db = layernorm_bwd(dys, x2, g, mean, rstd)
+            return _no_grad_like(ctx.shape, dy.dtype, dy.device), dg.to(ctx.pdtype), db.to(ctx.pdtype), None
         ps = _PS
         if ps is not None:
             dy2 = _as2d(dy.contiguous())
+            if ps.keep:
+                ctx.kept = dy2
             ps_layernorm(ps, dy2, x2, mean, rstd)
             dx, _, _ = layernorm_bwd(dy2, x2, g, mean, rstd, need_affine=False)
             return dx.view(ctx.shape), None, None, None
@@ -829,6 +917,12 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, weight = ctx.saved_tensors
+        rp = _PS2
+        if rp is not None:
+            dys = seg_scale_rows(_kept(ctx), rp.coef, x2.shape[0] // rp.coef.numel())
+            dw = linear_bwd_w(dys, x2).to(weight.dtype)
+            db = colsum(dys).to(weight.dtype) if ctx.has_bias else None
+            return _no_grad_like(ctx.in_shape, ctx.in_dtype, dy.device), dw, db, None, None
         dy2 = _as2d(dy.contiguous())
         if dy2.dtype != ctx.cdt:
             dy2 = cast(dy2, ctx.cdt)
@@ -838,6 +932,8 @@ class LinearFn(torch.autograd.Function):
             dx = cast(dx, ctx.in_dtype)
         ps = _PS
         if ps is not None:
+            if ps.keep:
+                ctx.kept = dy2
             ps_weight(ps, dy2, x2)
             if ctx.has_bias:
                 ps_bias(ps, dy2)
@@ -947,6 +1043,27 @@ class AttnBlockFn(_BlockFn):
         x2, g, mean, rstd, xn, qkv, o, lse, w_qkv, w_out = ctx.saved_tensors
         B, N, D, heads, dh, add_residual, cdt, has_ln, has_bo, ln_dtype, in_dtype = ctx.meta
         inner = heads * dh
+        rp = _PS2
+        if rp is not None:
+            # sum_i c_i g_i from the norm pass's tensors: rows of the 'narrow' operand of each product scaled by c
+            dy2, dqkv2, s_bq, s_ln = _kept(ctx)
+            xn_ = xn if xn is not None else x2
+            xs = seg_scale_rows(xn_, rp.coef, N)
+            dwo = dbo = dbq = dg = db = None
+            if w_out is not None:
+                dys = seg_scale_rows(dy2, rp.coef, N)
+                dwo, dwq = linear_bwd_w_pair(dys, o.view(B * N, inner), dqkv2, xs)
+                dwo = dwo.to(w_out.dtype)
+                if has_bo:
+                    dbo = colsum(dys).to(w_out.dtype)
+            else:
+                dwq = linear_bwd_w(dqkv2, xs)
+            if s_bq is not None:
+                dbq = seg_combine(s_bq, rp.coef).to(ctx.bqkv_dtype)
+            if has_ln:
+                db, dg = seg_combine(s_ln[0], rp.coef).to(ln_dtype), seg_combine(s_ln[1], rp.coef).to(ln_dtype)
+            return (_no_grad_like((B, N, D), in_dtype, dy.device), dg, db, dwq.to(w_qkv.dtype), dwo, dbo, None, None, None,
+                    None, None, dbq)
         dy2 = _as2d(dy.contiguous())
         if dy2.dtype != cdt:
             dy2 = cast(dy2, cdt)
@@ -963,14 +1080,17 @@ class AttnBlockFn(_BlockFn):
                 do = dy2
             dqkv2 = attn_bwd(qkv, o, do.view(B, N, inner), lse, B, N, heads, dh).view(B * N, 3 * inner)
             ps_weight(ps, dqkv2, xn_)
+            s_bq = s_ln = None
             if ctx.bqkv_dtype is not None:
-                ps_bias(ps, dqkv2)
+                s_bq = ps_bias(ps, dqkv2, want_sums=ps.keep)
             dxn = linear_bwd_x(dqkv2, compute_copy(w_qkv, cdt), w_t=weight_t(w_qkv, cdt))
             if has_ln:
-                ps_layernorm(ps, dxn, x2, mean, rstd)
+                s_ln = ps_layernorm(ps, dxn, x2, mean, rstd, want_sums=ps.keep)
                 dx, _, _ = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None, need_affine=False)
             else:
                 dx = add(dxn, dy2) if add_residual else dxn
+            if ps.keep:
+                ctx.kept = (dy2, dqkv2, s_bq, s_ln)
             dx = dx.view(B, N, D)
             if dx.dtype != in_dtype:
                 dx = cast(dx, in_dtype)
@@ -1094,6 +1214,9 @@ class FFBlockFn(_BlockFn):
                     y = add(y, x2.contiguous())
         ctx.whole = whole
         ctx.drop = drop
+        # what `u` holds: gelu'(pre-activation) (multiplied in by the backward epilogue), or, when the whole-block call ran
+        # with the "erf" pair, the pre-activation itself (the backward epilogue evaluates the derivative)
+        ctx.aux_epi = EPI_DGELU if (whole and lib.vitmi_get_gelu_mode()) else EPI_MULAUX
         ctx.save_for_backward(x2, g, mean, rstd, xn if ln_w is not None else None, u, h, w1, w2)
         ctx.meta = (shape, add_residual, cdt, ln_w is not None, ln_w.dtype if ln_w is not None else None, x.dtype)
         return y.view(*shape[:-1], w2.shape[0])
@@ -1102,6 +1225,21 @@ class FFBlockFn(_BlockFn):
     def backward(ctx, dy):
         x2, g, mean, rstd, xn, u, h, w1, w2 = ctx.saved_tensors
         shape, add_residual, cdt, has_ln, ln_dtype, in_dtype = ctx.meta
+        rp = _PS2
+        if rp is not None:
+            dy2, du, s_b1, s_ln = _kept(ctx)
+            seg = x2.shape[0] // rp.coef.numel()
+            xn_ = xn if xn is not None else x2
+            dys = seg_scale_rows(dy2, rp.coef, seg)
+            xs = seg_scale_rows(xn_, rp.coef, seg)
+            dw2, dw1 = linear_bwd_w_pair(dys, h, du, xs)
+            db2 = colsum(dys).to(w2.dtype)
+            db1 = seg_combine(s_b1, rp.coef).to(w1.dtype)
+            dg = db = None
+            if has_ln:
+                db, dg = seg_combine(s_ln[0], rp.coef).to(ln_dtype), seg_combine(s_ln[1], rp.coef).to(ln_dtype)
+            return (_no_grad_like(shape, in_dtype, dy.device), dg, db, dw1.to(w1.dtype), db1, dw2.to(w2.dtype), db2, None,
+                    None, None, None)
         dy2 = _as2d(dy.contiguous())
         if dy2.dtype != cdt:
             dy2 = cast(dy2, cdt)
@@ -1115,7 +1253,7 @@ class FFBlockFn(_BlockFn):
             dyd = dropout(dy2, drop[0], drop[2])
             dw2 = linear_bwd_w(dyd, h).to(w2.dtype)
             db2 = colsum(dyd).to(w2.dtype)
-            du = linear_bwd_x(dyd, compute_copy(w2, cdt), epi=EPI_MULAUX, aux=u, w_t=weight_t(w2, cdt))
+            du = linear_bwd_x(dyd, compute_copy(w2, cdt), epi=ctx.aux_epi, aux=u, w_t=weight_t(w2, cdt))
             dropout(du, drop[0], drop[1], out=du)
             dw1 = linear_bwd_w(du, xn).to(w1.dtype)
             db1 = colsum(du).to(w1.dtype)
@@ -1134,15 +1272,18 @@ class FFBlockFn(_BlockFn):
             xn_ = xn if xn is not None else x2
             ps_weight(ps, dy2, h)
             ps_bias(ps, dy2)
-            du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_MULAUX, aux=u, w_t=weight_t(w2, cdt))
+            du = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=ctx.aux_epi, aux=u, w_t=weight_t(w2, cdt))
             ps_weight(ps, du, xn_)
-            ps_bias(ps, du)
+            s_b1 = ps_bias(ps, du, want_sums=ps.keep)
             dxn = linear_bwd_x(du, compute_copy(w1, cdt), w_t=weight_t(w1, cdt))
+            s_ln = None
             if has_ln:
-                ps_layernorm(ps, dxn, x2, mean, rstd)
+                s_ln = ps_layernorm(ps, dxn, x2, mean, rstd, want_sums=ps.keep)
                 dx, _, _ = layernorm_bwd(dxn, x2, g, mean, rstd, dres=dy2 if add_residual else None, need_affine=False)
             else:
                 dx = add(dxn, dy2) if add_residual else dxn
+            if ps.keep:
+                ctx.kept = (dy2, du, s_b1, s_ln)
             dx = dx.view(shape)
             if dx.dtype != in_dtype:
                 dx = cast(dx, in_dtype)
@@ -1174,7 +1315,7 @@ class FFBlockFn(_BlockFn):
         dw2 = linear_bwd_w(dy2, h).to(w2.dtype)
         fuse_db2 = has_ln and add_residual
         db2 = None if fuse_db2 else colsum(dy2).to(w2.dtype)
-        du, db1 = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=EPI_MULAUX, aux=u, w_t=weight_t(w2, cdt),
+        du, db1 = linear_bwd_x(dy2, compute_copy(w2, cdt), epi=ctx.aux_epi, aux=u, w_t=weight_t(w2, cdt),
                                want_colsum=True)
         dw1 = linear_bwd_w(du, xn).to(w1.dtype)
         db1 = db1.to(w1.dtype)
@@ -1210,6 +1351,8 @@ class MeanPoolFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if _PS2 is not None:                # a replay forms no input gradients
+            return _no_grad_like((dout.shape[0], ctx.n, dout.shape[1]), dout.dtype, dout.device)
         dout = dout.contiguous()
         B, D = dout.shape
         dx = torch.empty((B, ctx.n, D), dtype=dout.dtype, device=dout.device)
