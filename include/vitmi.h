@@ -310,8 +310,13 @@ int vitmi_layernorm_bwd_static(const void* dy, const void* x, long long ldx, con
  * scores = (q k^T) * DH^-0.5 (scale after the matmul), softmax over keys, out = probs v.
  * lse [B,H,N] fp32 receives log-sum-exp of the scaled scores (kept for backward).
  * probs ([B,H,N,N] dt) may be NULL; when given it receives the post-softmax probabilities the
- * reference hands to forward hooks on Attention.attend (ViT.py:100) / attn_drop. */
-int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, int B, int N, int H, int DH,
+ * reference hands to forward hooks on Attention.attend (ViT.py:100) / attn_drop.
+ * layout: 0, or VITMI_QKV_HEAD_MAJOR when qkv is stored as head-major planes [3][H][B*N][DH] (what
+ * vitmi_attn_block_fwd writes for bf16 heads of 64: the [N][DH] matrix of one (q|k|v, image, head) is then contiguous);
+ * vitmi_attn_bwd also takes VITMI_DQKV_HEAD_MAJOR for the layout dqkv is WRITTEN in.  Planes need bf16 and DH = 64. */
+#define VITMI_QKV_HEAD_MAJOR 1
+#define VITMI_DQKV_HEAD_MAJOR 2
+int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, int B, int N, int H, int DH, int layout,
                    void* stream);
 /* dqkv from dout, recomputing the probabilities from qkv and lse.  dprobs ([B,H,N,N] dt, a gradient that reaches
  * the exported probabilities from outside: a loss on the attention maps, the hooks of vit_grad_rollout.py:38-56) may
@@ -324,7 +329,7 @@ int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, 
 long long vitmi_attn_bwd_workspace_bytes(int dt, int B, int N, int H, int DH);
 long long vitmi_attn_bwd_dprobs_workspace_bytes(int dt, int B, int N, int H, int DH);
 int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const void* dprobs,
-                   void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, void* stream);
+                   void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, int layout, void* stream);
 
 /* Whole encoder sub-blocks, each ONE call that enqueues the launches of the sub-block in order on the stream:
  *   ff block    y = x + W2 gelu(W1 LN(x) + b1) + b2       PreNorm(FeedForward) + residual, mymodel/ViT.py:58,65-73,120
@@ -348,13 +353,19 @@ int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const voi
 int vitmi_attn_block_fwd(int dt, int B, int N, int D, int H, int DH, const void* x, const float* gamma, const float* beta,
                          float eps, const void* w_qkv, const float* b_qkv, const void* w_out, const float* b_out,
                          void* xn, float* mean, float* rstd, void* qkv, void* o, float* lse, void* probs, void* y,
-                         void* stream);
+                         int qkv_layout, void* stream);
+/* The layout vitmi_attn_block_fwd should be asked to leave qkv in for this shape (VITMI_QKV_HEAD_MAJOR for bf16 heads
+ * of 64, else 0); the same value goes to vitmi_attn_block_bwd, or to vitmi_attn_bwd when the backward pass is driven
+ * step by step.  vitmi_debug_set_qkv_planes(mask): bit 0 = recommend planes for qkv, bit 1 = planes for the dqkv that
+ * vitmi_attn_block_bwd keeps in its workspace (default 3); process-wide, for benchmarking. */
+int vitmi_attn_block_qkv_layout(int dt, int B, int N, int D, int H, int DH);
+int vitmi_debug_set_qkv_planes(int mask);
 long long vitmi_attn_block_bwd_workspace_bytes(int dt, int B, int N, int D, int H, int DH);
 int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, const void* dy, const void* x, const void* xn,
                          const void* qkv, const void* o, const float* lse, const float* gamma, const float* mean,
                          const float* rstd, const void* w_qkv, const void* w_qkv_t, const void* w_out,
                          const void* w_out_t, void* dx, float* dgamma, float* dbeta, float* dw_qkv, float* db_qkv,
-                         float* dw_out, float* db_out, void* workspace, void* stream);
+                         float* dw_out, float* db_out, void* workspace, int qkv_layout, void* stream);
 
 /* The same two sub-blocks for inference (no autograd graph: model.eval() under torch.no_grad(), the mode of
  * mia_attn.py / vit_rollout.py / every evaluation loop of trainer.py), bf16 only, nothing kept for a backward pass.

@@ -262,3 +262,39 @@ def test_weight_gradient_workspace_holds_under_every_cu_reservation(T, P0, Q0, P
         check(lib.vitmi_set_reserved_cus(0))
     for a, b in results[1:]:
         assert rel_err(a, results[0][0]) < 1e-5 and rel_err(b, results[0][1]) < 1e-5
+
+
+@pytest.mark.parametrize("B,with_bias", [(128, False), (9, False), (32, True)])
+def test_attention_block_planes_equal_rows(B, with_bias):
+    """The attention sub-block with qkv / dqkv as head-major planes (the default for bf16 heads of 64) against the same
+    calls on the row layout (vitmi_debug_set_qkv_planes(0)): the GEMMs store and load the same values at other
+    addresses, so the output and every gradient are equal bit for bit.  B = 9: tokens no multiple of 64 (the paired
+    weight-gradient launch does not apply, the planes go through the single products); with_bias: the timm-style qkv
+    bias, whose gradient keeps dqkv in rows."""
+    from visiontransformer_amd import ops
+    from visiontransformer_amd._lib import lib
+    N, D, H = 197, 768, 12
+    g = torch.Generator().manual_seed(31 + B)
+    x = torch.randn(B, N, D, generator=g).to(DEV, torch.bfloat16).requires_grad_(True)
+    dy = torch.randn(B, N, D, generator=g).to(DEV, torch.bfloat16)
+    ln_w = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV).requires_grad_(True)
+    ln_b = (0.1 * torch.randn(D, generator=g)).to(DEV).requires_grad_(True)
+    wq = (torch.randn(3 * D, D, generator=g) * D ** -0.5).to(DEV).requires_grad_(True)
+    bq = (0.1 * torch.randn(3 * D, generator=g)).to(DEV).requires_grad_(True) if with_bias else None
+    wo = (torch.randn(D, D, generator=g) * D ** -0.5).to(DEV).requires_grad_(True)
+    bo = (0.1 * torch.randn(D, generator=g)).to(DEV).requires_grad_(True)
+    leaves = [t for t in (x, ln_w, ln_b, wq, wo, bo, bq) if t is not None]
+    res = {}
+    try:
+        for mask in (3, 1, 0):
+            lib.vitmi_debug_set_qkv_planes(mask)
+            for t in leaves:
+                t.grad = None
+            y, _ = ops.AttnBlockFn.apply(x, ln_w, ln_b, wq, wo, bo, H, 1e-5, True, False, torch.bfloat16, bq)
+            y.backward(dy)
+            res[mask] = [y.detach().clone()] + [t.grad.clone() for t in leaves]
+    finally:
+        lib.vitmi_debug_set_qkv_planes(3)
+    for mask in (3, 1):
+        for a, b in zip(res[mask], res[0]):
+            assert torch.equal(a, b), mask

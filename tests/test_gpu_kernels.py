@@ -300,6 +300,54 @@ def test_attention_backward_one_kernel_bf16(ops, B, N, H, DH):
         lib.vitmi_debug_set_attn_bwd_fused(2)
 
 
+@pytest.mark.parametrize("B,N,H,DH", [(40, 197, 12, 64), (3, 129, 2, 64), (6, 100, 3, 64), (2, 300, 2, 64), (70, 208, 4, 64)])
+def test_attention_head_major_planes_bf16(ops, B, N, H, DH):
+    # qkv / dqkv as head-major planes [3][H][B*N][64] (what the whole-block calls use for heads of 64): the same
+    # kernels on another addressing, so every result equals the row-layout one bit for bit -- forward (with and without
+    # export), every backward variant, planes in, planes out, and both
+    from visiontransformer_amd._lib import check, lib
+    dtype = torch.bfloat16
+    T, I = B * N, H * DH
+
+    def to_planes(t):        # [B, N, 3*I] -> [3, H, T, DH] flattened into the same number of elements
+        return t.view(T, 3, H, DH).permute(1, 2, 0, 3).contiguous().view(B, N, 3 * I)
+
+    def from_planes(t):
+        return t.view(3, H, T, DH).permute(2, 0, 1, 3).contiguous().view(B, N, 3 * I)
+
+    qd = rnd(B, N, 3 * I, seed=11, scale=1.5).to(DEV, dtype)
+    dod = rnd(B, N, I, seed=12).to(DEV, dtype)
+    qp = to_planes(qd)
+    assert torch.equal(from_planes(qp), qd)
+    export = N <= 256
+    o, lse, probs = ops.attn_fwd(qd, B, N, H, DH, export)
+    o2, lse2, probs2 = ops.attn_fwd(qp, B, N, H, DH, export, layout=1)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2) and (not export or torch.equal(probs, probs2))
+    p = ops._p
+    try:
+        for mode in (0, 1, 2):
+            lib.vitmi_debug_set_attn_bwd_fused(mode)
+            want = ops.attn_bwd(qd, o, dod, lse, B, N, H, DH)
+            for layout in (1, 2, 3):
+                src = qp if layout & 1 else qd
+                got = torch.full_like(qd, float("nan"))
+                ws = ops._ws(lib.vitmi_attn_bwd_workspace_bytes(1, B, N, H, DH), DEV)
+                check(lib.vitmi_attn_bwd(p(src), p(o), p(dod), p(lse), None, p(got), p(ws), 1, B, N, H, DH, layout,
+                                         ops._stream()), "vitmi_attn_bwd")
+                got = from_planes(got) if layout & 2 else got
+                assert torch.equal(got, want), (mode, layout)
+    finally:
+        lib.vitmi_debug_set_attn_bwd_fused(2)
+
+
+def test_attention_planes_need_bf16_heads_of_64(ops):
+    from visiontransformer_amd._lib import VitmiError
+    with pytest.raises(VitmiError, match="head-major"):
+        ops.attn_fwd(torch.zeros(2, 65, 3 * 96, device=DEV, dtype=torch.bfloat16), 2, 65, 12, 8, False, layout=1)
+    with pytest.raises(VitmiError, match="head-major"):
+        ops.attn_fwd(torch.zeros(2, 65, 3 * 64, device=DEV), 2, 65, 1, 64, False, layout=1)
+
+
 def test_attention_backward_one_kernel_with_reserved_compute_units(ops):
     # vitmi_set_reserved_cus leaves compute units to a collective: the one-workgroup-per-CU backward launches that many
     # fewer workgroups and each walks more pairs; same gradients bit for bit

@@ -123,7 +123,7 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     # argument validation happens before any HIP call
     rc = _lib.lib.vitmi_gemm(1, 0, 4, 4, None, 1, 1, None, 1, 1, None, 4, 1, 0, None, None, 0, None, 0, None)
     assert rc == -1 and b"null operand" in _lib.lib.vitmi_last_error()
-    rc = _lib.lib.vitmi_attn_fwd(1, 1, 1, None, 1, 1, 700, 1, 64, None)
+    rc = _lib.lib.vitmi_attn_fwd(1, 1, 1, None, 1, 1, 700, 1, 64, 0, None)
     assert rc == -3 and b"608" in _lib.lib.vitmi_last_error()
     with pytest.raises(_lib.VitmiError):
         _lib.check(rc, "attn")

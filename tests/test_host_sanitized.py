@@ -55,8 +55,8 @@ assert lib.vitmi_layernorm_bwd_workspace_bytes(2 ** 40, 1024) > 0
 assert lib.vitmi_rollout_workspace_bytes(12, 256, 197) > 0
 assert lib.vitmi_tokens_assemble_bwd_workspace_bytes(197, 768) > 0
 # argument checks: a clean error code and a message, never a crash
-assert lib.vitmi_attn_fwd(None, None, None, None, _lib.BF16, 1, 1, 1, 64, None) != 0 and lib.vitmi_last_error()
-assert lib.vitmi_attn_bwd(None, None, None, None, None, None, None, _lib.BF16, 1, 1, 1, 64, None) != 0
+assert lib.vitmi_attn_fwd(None, None, None, None, _lib.BF16, 1, 1, 1, 64, 0, None) != 0 and lib.vitmi_last_error()
+assert lib.vitmi_attn_bwd(None, None, None, None, None, None, None, _lib.BF16, 1, 1, 1, 64, 0, None) != 0
 assert lib.vitmi_set_reserved_cus(7) != 0 and b"multiple of 8" in lib.vitmi_last_error()
 assert lib.vitmi_set_reserved_cus(0) == 0
 for knob in ("vitmi_debug_set_nt_group", "vitmi_debug_set_nt_tail_split", "vitmi_debug_set_gelu_pair",

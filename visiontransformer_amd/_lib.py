@@ -72,9 +72,11 @@ SIGNATURES = {
     "vitmi_ff_block_fwd": (I, [I, I, I, I, P, P, P, F, P, P, P, P, P, P, P, P, P, P, P]),
     "vitmi_ff_block_bwd_workspace_bytes": (L, [I, I, I, I]),
     "vitmi_ff_block_bwd": (I, [I, I, I, I] + [P] * 21),
-    "vitmi_attn_block_fwd": (I, [I, I, I, I, I, I, P, P, P, F] + [P] * 13),
+    "vitmi_attn_block_fwd": (I, [I, I, I, I, I, I, P, P, P, F] + [P] * 12 + [I, P]),
+    "vitmi_attn_block_qkv_layout": (I, [I, I, I, I, I, I]),
+    "vitmi_debug_set_qkv_planes": (I, [I]),
     "vitmi_attn_block_bwd_workspace_bytes": (L, [I, I, I, I, I, I]),
-    "vitmi_attn_block_bwd": (I, [I, I, I, I, I, I] + [P] * 22),
+    "vitmi_attn_block_bwd": (I, [I, I, I, I, I, I] + [P] * 21 + [I, P]),
     "vitmi_transpose_cast_multi": (I, [P, P, I, L, P]),
     "vitmi_wgrad_sqnorm_workspace_bytes": (L, [I, I, I, I, I]),
     "vitmi_wgrad_sqnorm": (I, [I, I, I, I, I, P, L, P, L, P, P, P]),
@@ -96,10 +98,10 @@ SIGNATURES = {
     "vitmi_layernorm_bwd_workspace_bytes": (L, [L, I]),
     "vitmi_layernorm_bwd": (I, [P, P, L, P, P, P, P, P, P, P, P, P, I, L, I, P]),
     "vitmi_layernorm_bwd_static": (I, [P, P, L, P, P, P, P, P, P, P, P, I, L, I, P]),
-    "vitmi_attn_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "vitmi_attn_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "vitmi_attn_bwd_workspace_bytes": (L, [I, I, I, I, I]),
     "vitmi_attn_bwd_dprobs_workspace_bytes": (L, [I, I, I, I, I]),
-    "vitmi_attn_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "vitmi_attn_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "vitmi_meanpool_fwd": (I, [P, P, I, I, I, I, P]),
     "vitmi_meanpool_bwd": (I, [P, P, I, I, I, I, P]),
     "vitmi_add": (I, [P, P, P, I, L, P]),

@@ -177,6 +177,16 @@ __device__ __forceinline__ void stage_img2(const bf16_t* a, long long lda, bf16_
     }
 }
 
+// Where q / k / v (which = 0 / 1 / 2) of head h of image b start, and the row stride.  T == 0: the rows of to_qkv's
+// output, [tokens][3][H][DH] (a head's rows are 2*DH-byte pieces 6*H*DH bytes apart).  T > 0, the number of tokens in
+// the batch: head-major planes [3][H][T][DH], so the [N][DH] matrix of one (which, image, head) is contiguous -- what the
+// projection GEMM's epilogue writes for heads of 64 and the GEMMs behind the backward pass read.
+__device__ __forceinline__ long long qkv_off(int which, int b, int h, int N, int H, int DH, long long T) {
+    if (T > 0) return (((long long)which * H + h) * T + (long long)b * N) * DH;
+    return (long long)b * N * 3 * H * DH + (long long)which * H * DH + (long long)h * DH;
+}
+__device__ __forceinline__ long long qkv_ld(int H, int DH, long long T) { return T > 0 ? (long long)DH : 3ll * H * DH; }
+
 // Workgroups are dealt to the 8 XCDs round-robin by blockIdx.  This returns the (image, head) pair index a block
 // works on such that each XCD walks a contiguous range of pairs: the heads of one image, whose q/k/v rows are
 // adjacent 128-byte pieces of the same qkv rows, are then fetched by one XCD's L2 close together in time.
@@ -324,7 +334,7 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
 template <int DH, int NC, bool EXPORT, int THREADS, int HPW>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8 ? 4 : (NC <= 16 ? 2 : 1), NC <= 8 ? 4 : (NC <= 16 ? 2 : 1)))) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                             float* __restrict__ lse, bf16_t* __restrict__ probs, int N,
-                                                            int H, float scale) {
+                                                            int H, float scale, long long qT) {
     using A = AttnDims<DH>;
     constexpr int NP = NC * 32, IMG = NP * A::W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -333,10 +343,10 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8
     const int pair0 = xcd_block_order() * HPW;
     const int b = pair0 / H, h0 = pair0 % H;
     const int I = H * DH;
-    const long long ld = 3ll * I;
-    const bf16_t* qb = qkv + (long long)b * N * ld + h0 * DH;
-    const bf16_t* kb = qb + I;
-    const bf16_t* vb = qb + 2 * I;
+    const long long ld = qkv_ld(H, DH, qT);          // head-major (qT > 0) only with HPW == 1
+    const bf16_t* qb = qkv + qkv_off(0, b, h0, N, H, DH, qT);
+    const bf16_t* kb = qkv + qkv_off(1, b, h0, N, H, DH, qT);
+    const bf16_t* vb = qkv + qkv_off(2, b, h0, N, H, DH, qT);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int ntq = (N + 15) >> 4, total = HPW * ntq;
@@ -369,7 +379,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
                                                                 const bf16_t* __restrict__ dout,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta_in,
-                                                                bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                                bf16_t* __restrict__ dqkv, int N, int H, float scale,
+                                                                long long qT, long long dT) {
     using A = AttnDims<DH>;
     constexpr int NP = NC * 32, IMG = NP * A::W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -381,10 +392,10 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
     const int pair0 = xcd_block_order() * HPW;
     const int b = pair0 / H, h0 = pair0 % H;
     const int I = H * DH;
-    const long long ld = 3ll * I;
-    const bf16_t* qb = qkv + (long long)b * N * ld + h0 * DH;
-    const bf16_t* kb = qb + I;
-    const bf16_t* vb = qb + 2 * I;
+    const long long ld = qkv_ld(H, DH, qT), ldd = qkv_ld(H, DH, dT);
+    const bf16_t* qb = qkv + qkv_off(0, b, h0, N, H, DH, qT);
+    const bf16_t* kb = qkv + qkv_off(1, b, h0, N, H, DH, qT);
+    const bf16_t* vb = qkv + qkv_off(2, b, h0, N, H, DH, qT);
     const bf16_t* dob = dout + (long long)b * N * I + h0 * DH;
     // lse (in log2 units) and delta = rowsum(dO * O) per query, the latter left by the dQ kernel; padded queries
     // get p = 0
@@ -455,8 +466,8 @@ __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const b
             }
         }
         if (key < N) {
-            bf16_t* dk = dqkv + ((long long)b * N + key) * ld + I + h * DH;
-            bf16_t* dv = dk + I;
+            bf16_t* dk = dqkv + qkv_off(1, b, h, N, H, DH, dT) + (long long)key * ldd;
+            bf16_t* dv = dqkv + qkv_off(2, b, h, N, H, DH, dT) + (long long)key * ldd;
 #pragma unroll
             for (int dt = 0; dt < A::DT; ++dt) {
                 const int d = dt * 16 + fg * 4;
@@ -482,7 +493,8 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(NC
                                                                const bf16_t* __restrict__ dout,
                                                                const float* __restrict__ lse,
                                                                float* __restrict__ delta_out,
-                                                               bf16_t* __restrict__ dqkv, int N, int H, float scale) {
+                                                               bf16_t* __restrict__ dqkv, int N, int H, float scale,
+                                                               long long qT, long long dT) {
     using A = AttnDims<DH>;
     constexpr int NP = NC * 32, IMG = NP * A::W;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -492,10 +504,10 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(NC
     const int pair0 = xcd_block_order() * HPW;
     const int b = pair0 / H, h0 = pair0 % H;
     const int I = H * DH;
-    const long long ld = 3ll * I;
-    const bf16_t* qb = qkv + (long long)b * N * ld + h0 * DH;
-    const bf16_t* kb = qb + I;
-    const bf16_t* vb = qb + 2 * I;
+    const long long ld = qkv_ld(H, DH, qT), ldd = qkv_ld(H, DH, dT);
+    const bf16_t* qb = qkv + qkv_off(0, b, h0, N, H, DH, qT);
+    const bf16_t* kb = qkv + qkv_off(1, b, h0, N, H, DH, qT);
+    const bf16_t* vb = qkv + qkv_off(2, b, h0, N, H, DH, qT);
     const bf16_t* ob = out + (long long)b * N * I + h0 * DH;
     const bf16_t* dob = dout + (long long)b * N * I + h0 * DH;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -568,7 +580,7 @@ __global__ __launch_bounds__(ATTN_THREADS) __attribute__((amdgpu_waves_per_eu(NC
                                                                   0, 0);
         }
         if (q < N) {
-            bf16_t* dq = dqkv + ((long long)b * N + q) * ld + h * DH;
+            bf16_t* dq = dqkv + qkv_off(0, b, h, N, H, DH, dT) + (long long)q * ldd;
 #pragma unroll
             for (int dt = 0; dt < A::DT; ++dt) {
                 const int d = dt * 16 + fg * 4;
@@ -628,7 +640,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_fused_bf16_kernel(cons
                                                                    const bf16_t* __restrict__ out,
                                                                    const bf16_t* __restrict__ dout,
                                                                    const float* __restrict__ lse,
-                                                                   bf16_t* __restrict__ dqkv, int N, int H, int npairs, float scale) {
+                                                                   bf16_t* __restrict__ dqkv, int N, int H, int npairs, float scale,
+                                                                   long long qT, long long dT) {
     constexpr int DH = 64;
     using A = AttnDims<DH>;
     constexpr int NP = NC * 32, IMG = NP * A::W, DSB = NP * 32;
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_fused_bf16_kernel(cons
     float* delta = lse2 + NP;
 
     const int I = H * DH;
-    const long long ld = 3ll * I;
+    const long long ld = qkv_ld(H, DH, qT), ldd = qkv_ld(H, DH, dT);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntk = (N + 15) >> 4;                            // the launcher guarantees ntk <= FUSED_TASK_WAVE0
     const bool owner = wave < ntk;
@@ -653,9 +666,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_fused_bf16_kernel(cons
     // range of pairs (the heads of a few images)
     for (int pair = xcd_block_order(); pair < npairs; pair += gridDim.x) {
         const int b = pair / H, h = pair % H;
-        const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
-        const bf16_t* kb = qb + I;
-        const bf16_t* vb = qb + 2 * I;
+        const bf16_t* qb = qkv + qkv_off(0, b, h, N, H, DH, qT);
+        const bf16_t* kb = qkv + qkv_off(1, b, h, N, H, DH, qT);
+        const bf16_t* vb = qkv + qkv_off(2, b, h, N, H, DH, qT);
         const bf16_t* ob = out + (long long)b * N * I + h * DH;
         const bf16_t* dob = dout + (long long)b * N * I + h * DH;
         // everything derived from the thread index is formed again per pair: kept across the loop, the LDS offsets of
@@ -752,8 +765,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_fused_bf16_kernel(cons
                 if (!(VITMI_FUSED_ABL & 4)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if (owner && key < N) {
-                bf16_t* dk = dqkv + ((long long)b * N + key) * ld + I + h * DH;
-                bf16_t* dv = dk + I;
+                bf16_t* dk = dqkv + qkv_off(1, b, h, N, H, DH, dT) + (long long)key * ldd;
+                bf16_t* dv = dqkv + qkv_off(2, b, h, N, H, DH, dT) + (long long)key * ldd;
 #pragma unroll
                 for (int dt = 0; dt < A::DT; ++dt) {
                     const int d = dt * 16 + fg * 4;
@@ -816,7 +829,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_fused_bf16_kernel(cons
                             bf16x4 v;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[i][j][r] * scale);
-                            *reinterpret_cast<bf16x4*>(dqkv + ((long long)b * N + q) * ld + h * DH + (2 * tw + i) * 16 + fg * 4) = v;
+                            *reinterpret_cast<bf16x4*>(dqkv + qkv_off(0, b, h, N, H, DH, dT) + (long long)q * ldd + (2 * tw + i) * 16 + fg * 4) = v;
                         }
                     }
                 }
@@ -851,7 +864,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
                                                                   const bf16_t* __restrict__ dout,
                                                                   const float* __restrict__ lse,
                                                                   bf16_t* __restrict__ dqkv, int N, int H, int npairs,
-                                                                  float scale) {
+                                                                  float scale, long long qT, long long dT) {
     constexpr int DH = 64, NC = PIPE_NC, ROWS = PIPE_ROWS, NQ = PIPE_NQ;
     using A = AttnDims<DH>;
     constexpr int IMG = ROWS * A::W, DSB = ROWS * 32, PCS = ROWS * A::CPR;   // PCS: 16-byte pieces of an image
@@ -864,7 +877,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
     float* lsd = reinterpret_cast<float*>(dsb0 + 2 * DSB);    // [set][lse in log2 units | delta][NQ]
 
     const int I = H * DH;
-    const long long ld = 3ll * I;
+    const long long ld = qkv_ld(H, DH, qT), ldd = qkv_ld(H, DH, dT);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntk = (N + 15) >> 4;                            // <= 13
     const bool owner = wave < ntk;
@@ -881,13 +894,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
         // the first pair arrives the plain way: all four matrices at once
         const int tid = threadIdx.x, lane = tid & 63, fr = lane & 15, fg = lane >> 4;
         const int b = pair / H, h = pair % H;
-        const bf16_t* qb = qkv + (long long)b * N * ld + h * DH;
+        const bf16_t* qb = qkv + qkv_off(0, b, h, N, H, DH, qT);
+        const bf16_t* kb = qkv + qkv_off(1, b, h, N, H, DH, qT);
+        const bf16_t* vb = qkv + qkv_off(2, b, h, N, H, DH, qT);
         const bf16_t* ob = out + (long long)b * N * I + h * DH;
         const bf16_t* dob = dout + (long long)b * N * I + h * DH;
 #pragma unroll
         for (int ks = 0; ks < A::KS; ++ks) {
-            kf[ks] = global_frag<DH>(qb + I, ld, owner ? wave * 16 + fr : N, N, ks, fg);
-            vf[ks] = global_frag<DH>(qb + 2 * I, ld, owner ? wave * 16 + fr : N, N, ks, fg);
+            kf[ks] = global_frag<DH>(kb, ld, owner ? wave * 16 + fr : N, N, ks, fg);
+            vf[ks] = global_frag<DH>(vb, ld, owner ? wave * 16 + fr : N, N, ks, fg);
         }
         if (tid < NQ) lsd[tid] = tid < N ? lse[((long long)b * H + h) * N + tid] * LOG2E : 1e30f;
         bf16x8 vq[2], vk[2], vd[2], vo[2];
@@ -898,7 +913,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
             vq[i] = vk[i] = vd[i] = vo[i] = zero8();
             if (c < PCS && r < N) {
                 vq[i] = *reinterpret_cast<const bf16x8*>(qb + (long long)r * ld + col);
-                vk[i] = *reinterpret_cast<const bf16x8*>(qb + I + (long long)r * ld + col);
+                vk[i] = *reinterpret_cast<const bf16x8*>(kb + (long long)r * ld + col);
                 vd[i] = *reinterpret_cast<const bf16x8*>(dob + (long long)r * I + col);
                 vo[i] = *reinterpret_cast<const bf16x8*>(ob + (long long)r * I + col);
             }
@@ -927,7 +942,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
     struct Ctx {
         int b, h;
         bool has_next;
-        const bf16_t *qn, *on, *don;          // next pair: q (k = +I, v = +2I), O, dO
+        const bf16_t *qn, *kn, *vn, *on, *don;    // next pair: q, k, v, O, dO
+        bf16_t *dq, *dk, *dv;                     // this pair's gradient rows (row stride ldd)
         const float* lsen;
         const bf16_t *Qs, *dOs;
         bf16_t *Qn, *dOn;
@@ -940,7 +956,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
         x.h = pair % H;
         x.has_next = pair + G < npairs;
         const int nb = (pair + G) / H, nh = (pair + G) % H;
-        x.qn = qkv + (long long)nb * N * ld + nh * DH;
+        x.qn = qkv + qkv_off(0, nb, nh, N, H, DH, qT);
+        x.kn = qkv + qkv_off(1, nb, nh, N, H, DH, qT);
+        x.vn = qkv + qkv_off(2, nb, nh, N, H, DH, qT);
+        x.dq = dqkv + qkv_off(0, x.b, x.h, N, H, DH, dT);
+        x.dk = dqkv + qkv_off(1, x.b, x.h, N, H, DH, dT);
+        x.dv = dqkv + qkv_off(2, x.b, x.h, N, H, DH, dT);
         x.on = out + (long long)nb * N * I + nh * DH;
         x.don = dout + (long long)nb * N * I + nh * DH;
         x.lsen = lse + ((long long)nb * H + nh) * N;
@@ -963,7 +984,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
         for (int i = 0; i < 2; ++i) {
             const int p = i * FUSED_THREADS + tl, r = p >> 3, col = (p & 7) * 8;
             bf16x8 v = zero8();
-            if (p < PCS && r < N) v = *reinterpret_cast<const bf16x8*>(x.qn + I + (long long)r * ld + col);
+            if (p < PCS && r < N) v = *reinterpret_cast<const bf16x8*>(x.kn + (long long)r * ld + col);
             if (i == 0) kp0 = v; else kp1 = v;
         }
     };
@@ -1020,8 +1041,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
                         // the old fragments have served their last product
 #pragma unroll
                         for (int ks = 0; ks < A::KS; ++ks) {
-                            kf[ks] = global_frag<DH>(x.qn + I, ld, key, N, ks, fg);
-                            vf[ks] = global_frag<DH>(x.qn + 2 * I, ld, key, N, ks, fg);
+                            kf[ks] = global_frag<DH>(x.kn, ld, key, N, ks, fg);
+                            vf[ks] = global_frag<DH>(x.vn, ld, key, N, ks, fg);
                         }
                     }
                     // element j is query 32c + 8fg + j of key `key`; keys past N must not reach dQ
@@ -1060,8 +1081,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if (owner && key < N) {
-                bf16_t* dk = dqkv + ((long long)x.b * N + key) * ld + I + x.h * DH;
-                bf16_t* dv = dk + I;
+                bf16_t* dk = x.dk + (long long)key * ldd;
+                bf16_t* dv = x.dv + (long long)key * ldd;
 #pragma unroll
                 for (int dt = 0; dt < A::DT; ++dt) {
                     const int d = dt * 16 + fg * 4;
@@ -1176,7 +1197,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void attn_bwd_pipe_bf16_kernel(const
                             bf16x4 v;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = (bf16_t)(acc[i][j][r] * scale);
-                            *reinterpret_cast<bf16x4*>(dqkv + ((long long)x.b * N + q) * ld + x.h * DH + (2 * tw + i) * 16 + fg * 4) = v;
+                            *reinterpret_cast<bf16x4*>(x.dq + (long long)q * ldd + (2 * tw + i) * 16 + fg * 4) = v;
                         }
                     }
                 }
@@ -1415,6 +1436,10 @@ __global__ __launch_bounds__(256) void attn_dprobs_rows_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------- dispatch helpers
+// layout of the call being dispatched (set by the entry points below, read where the kernels are launched): tokens in
+// the batch when qkv / dqkv are head-major planes, 0 for the rows of to_qkv's output
+thread_local long long tl_qT = 0, tl_dT = 0;
+
 inline int pick_nc(int N) {
     const int need = (N + 31) / 32;
     // 1..8 exact (every chunk holds a real key); 12, 16, 19 chunks for sequences up to 608 tokens, where the whole
@@ -1474,7 +1499,7 @@ int launch_fwd_t(const void* qkv, void* out, float* lse, void* probs, int B, int
                         "vitmi_attn_fwd: LDS attribute");
     if (rc != VITMI_OK) return rc;
     hipLaunchKernelGGL((attn_fwd_bf16_kernel<DH, NC, EXPORT, THREADS, HPW>), dim3(B * H / HPW), dim3(THREADS), sm, s,
-                       (const bf16_t*)qkv, (bf16_t*)out, lse, (bf16_t*)probs, N, H, scale);
+                       (const bf16_t*)qkv, (bf16_t*)out, lse, (bf16_t*)probs, N, H, scale, tl_qT);
     VITMI_LAUNCH_CHECK("vitmi_attn_fwd(bf16)");
     return VITMI_OK;
 }
@@ -1520,10 +1545,11 @@ int launch_bwd_t(const void* qkv, const void* out, const void* dout, const float
     if (rc != VITMI_OK) return rc;
     // dQ first: it leaves delta = rowsum(dO * O) per query in the workspace for the dK, dV kernel
     hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<DH, NC, HPW>), dim3(B * H / HPW), dim3(ATTN_THREADS), s2, s,
-                       (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+                       (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale, tl_qT,
+                       tl_dT);
     VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dq, bf16)");
     hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<DH, NC, HPW>), dim3(B * H / HPW), dim3(ATTN_THREADS), s1, s,
-                       (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale);
+                       (const bf16_t*)qkv, (const bf16_t*)dout, lse, delta, (bf16_t*)dqkv, N, H, scale, tl_qT, tl_dT);
     VITMI_LAUNCH_CHECK("vitmi_attn_bwd(dkv, bf16)");
     return VITMI_OK;
 }
@@ -1564,7 +1590,7 @@ int launch_bwd_fused_t(const void* qkv, const void* out, const void* dout, const
     cus = fused_grid_limit(cus);
     const int grid = B * H < cus ? B * H : cus;     // one workgroup fills a compute unit
     hipLaunchKernelGGL((attn_bwd_fused_bf16_kernel<NC>), dim3(grid), dim3(FUSED_THREADS), sm, s, (const bf16_t*)qkv,
-                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, B * H, scale);
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, B * H, scale, tl_qT, tl_dT);
     VITMI_LAUNCH_CHECK("vitmi_attn_bwd(fused, bf16)");
     return VITMI_OK;
 }
@@ -1579,7 +1605,7 @@ int launch_bwd_pipe(const void* qkv, const void* out, const void* dout, const fl
     cus = fused_grid_limit(cus);
     const int grid = B * H < cus ? B * H : cus;     // one workgroup fills a compute unit
     hipLaunchKernelGGL(attn_bwd_pipe_bf16_kernel, dim3(grid), dim3(FUSED_THREADS), PIPE_LDS, s, (const bf16_t*)qkv,
-                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, B * H, scale);
+                       (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, N, H, B * H, scale, tl_qT, tl_dT);
     VITMI_LAUNCH_CHECK("vitmi_attn_bwd(pipelined, bf16)");
     return VITMI_OK;
 }
@@ -1648,11 +1674,24 @@ extern "C" int vitmi_debug_set_attn_bwd_fused(int on) {
     return VITMI_OK;
 }
 
+// head-major planes exist for the bf16 kernels with heads of 64 (one (image, head) pair per workgroup)
+static int check_layout(const char* who, int layout, int dt, int DH, bool dprobs) {
+    VITMI_CHECK_ARG(layout >= 0 && layout <= 3, "%s: bad layout %d", who, layout);
+    if (layout && (dt != VITMI_BF16 || DH != 64 || dprobs)) {
+        vitmi_set_error("%s: the head-major qkv layout needs bf16 heads of 64 (and no gradient on the probabilities)", who);
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    return VITMI_OK;
+}
+
 extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* probs, int dt, int B, int N, int H, int DH,
-                              void* stream) {
+                              int layout, void* stream) {
     VITMI_CHECK_ARG(qkv && out && lse, "vitmi_attn_fwd: null pointer");
     int rc = check_common("vitmi_attn_fwd", dt, B, N, H, DH);
     if (rc != VITMI_OK) return rc;
+    rc = check_layout("vitmi_attn_fwd", layout, dt, DH, false);
+    if (rc != VITMI_OK) return rc;
+    tl_qT = (layout & VITMI_QKV_HEAD_MAJOR) ? (long long)B * N : 0;
     hipStream_t s = as_stream(stream);
     ProfScope prof(VITMI_FAM_ATTN_FWD, s, 4.0 * B * H * (double)N * N * DH);
     if (dt == VITMI_F32) {
@@ -1778,12 +1817,16 @@ static int attn_bwd_from_dout(const void* qkv, const void* out, const void* dout
 }
 
 extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const void* dprobs,
-                              void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, void* stream) {
+                              void* dqkv, void* workspace, int dt, int B, int N, int H, int DH, int layout, void* stream) {
     VITMI_CHECK_ARG(qkv && lse && dqkv, "vitmi_attn_bwd: null pointer");
     VITMI_CHECK_ARG(dout || dprobs, "vitmi_attn_bwd: neither dout nor dprobs");
     VITMI_CHECK_ARG(!dout || out, "vitmi_attn_bwd: dout needs out");
     int rc = check_common("vitmi_attn_bwd", dt, B, N, H, DH);
     if (rc != VITMI_OK) return rc;
+    rc = check_layout("vitmi_attn_bwd", layout, dt, DH, dprobs != nullptr);
+    if (rc != VITMI_OK) return rc;
+    tl_qT = (layout & VITMI_QKV_HEAD_MAJOR) ? (long long)B * N : 0;
+    tl_dT = (layout & VITMI_DQKV_HEAD_MAJOR) ? (long long)B * N : 0;
     hipStream_t s = as_stream(stream);
     if (!dprobs) return attn_bwd_from_dout(qkv, out, dout, lse, dqkv, workspace, dt, B, N, H, DH, s);
     VITMI_CHECK_ARG(workspace, "vitmi_attn_bwd: dprobs needs the workspace of vitmi_attn_bwd_dprobs_workspace_bytes");

@@ -87,18 +87,49 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
 }
 
 // ------------------------------------------------------------------------------------------- attention block
+bool vitmi_qkv_planes_ok(int dt, int B, int N, int D, int H, int DH, const void* x, const void* w_qkv, const void* qkv);
+int vitmi_gemm_to_planes(int T, int N, int K, const void* xn, const void* w, const float* bias, void* planes, void* stream);
+int vitmi_gemm_from_planes(int T, int D, int I3, const void* dqkv_planes, const void* w_t, void* dxn, void* stream);
+int vitmi_gemm_wgrad_pair_planes(int T, int P0, int Q0, const void* U0, long long ldu0, const void* V0, long long ldv0,
+                                 float* C0, int P1, int Q1, const void* U1_planes, const void* V1, long long ldv1, float* C1,
+                                 void* workspace, void* stream);
+
+// Head-major planes for qkv (bit 0) and, inside the backward call, for dqkv (bit 1): heads of 64 in bf16.  The
+// (image, head) matrices the attention kernels read are then contiguous 2 * N * 64-byte blocks instead of 128-byte
+// pieces 6 * H * 64 bytes apart, and so are the 64-deep k-blocks of the A operand of the input-gradient product.
+static int g_qkv_planes = 3;
+extern "C" int vitmi_debug_set_qkv_planes(int mask) {
+    g_qkv_planes = mask & 3;
+    return VITMI_OK;
+}
+extern "C" int vitmi_attn_block_qkv_layout(int dt, int B, int N, int D, int H, int DH) {
+    (void)B;
+    (void)N;
+    (void)H;
+    return ((g_qkv_planes & 1) && dt == VITMI_BF16 && DH == 64 && D % 8 == 0) ? VITMI_QKV_HEAD_MAJOR : 0;
+}
+
 extern "C" int vitmi_attn_block_fwd(int dt, int B, int N, int D, int H, int DH, const void* x, const float* gamma,
                                     const float* beta, float eps, const void* w_qkv, const float* b_qkv,
                                     const void* w_out, const float* b_out, void* xn, float* mean, float* rstd, void* qkv,
-                                    void* o, float* lse, void* probs, void* y, void* stream) {
+                                    void* o, float* lse, void* probs, void* y, int qkv_layout, void* stream) {
     VITMI_CHECK_ARG(x && gamma && beta && w_qkv && w_out && xn && mean && rstd && qkv && o && lse && y,
                     "vitmi_attn_block_fwd: null pointer");
     VITMI_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && DH > 0, "vitmi_attn_block_fwd: bad shape");
+    VITMI_CHECK_ARG(qkv_layout == 0 || qkv_layout == VITMI_QKV_HEAD_MAJOR, "vitmi_attn_block_fwd: bad qkv layout %d", qkv_layout);
     const int rows = B * N, I = H * DH;
     STEP(vitmi_layernorm_fwd(x, D, gamma, beta, xn, mean, rstd, dt, rows, D, eps, stream));
-    STEP(vitmi_gemm(dt, rows, 3 * I, D, xn, D, 1, w_qkv, D, 1, qkv, 3 * I, dt, VITMI_EPI_NONE, b_qkv, nullptr, 0, nullptr,
-                    0, stream));
-    STEP(vitmi_attn_fwd(qkv, o, lse, probs, dt, B, N, H, DH, stream));
+    if (qkv_layout) {
+        if (!vitmi_qkv_planes_ok(dt, B, N, D, H, DH, xn, w_qkv, qkv)) {
+            vitmi_set_error("vitmi_attn_block_fwd: head-major qkv needs bf16, heads of 64, D %% 8 == 0 and 16-byte aligned operands");
+            return VITMI_ERR_UNSUPPORTED;
+        }
+        STEP(vitmi_gemm_to_planes(rows, 3 * I, D, xn, w_qkv, b_qkv, qkv, stream));
+    } else {
+        STEP(vitmi_gemm(dt, rows, 3 * I, D, xn, D, 1, w_qkv, D, 1, qkv, 3 * I, dt, VITMI_EPI_NONE, b_qkv, nullptr, 0, nullptr,
+                        0, stream));
+    }
+    STEP(vitmi_attn_fwd(qkv, o, lse, probs, dt, B, N, H, DH, qkv_layout, stream));
     STEP(vitmi_gemm(dt, rows, D, I, o, I, 1, w_out, I, 1, y, D, dt, VITMI_EPI_NONE, b_out, x, D, nullptr, 0, stream));
     return VITMI_OK;
 }
@@ -119,19 +150,30 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
                                     const float* mean, const float* rstd, const void* w_qkv, const void* w_qkv_t,
                                     const void* w_out, const void* w_out_t, void* dx, float* dgamma, float* dbeta,
                                     float* dw_qkv, float* db_qkv, float* dw_out, float* db_out, void* workspace,
-                                    void* stream) {
+                                    int qkv_layout, void* stream) {
     VITMI_CHECK_ARG(dy && x && xn && qkv && o && lse && gamma && mean && rstd && w_qkv && w_out && dx && dgamma && dbeta &&
                         dw_qkv && dw_out && workspace,
                     "vitmi_attn_block_bwd: null pointer");
     VITMI_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && DH > 0, "vitmi_attn_block_bwd: bad shape");
+    VITMI_CHECK_ARG(qkv_layout == 0 || qkv_layout == VITMI_QKV_HEAD_MAJOR, "vitmi_attn_block_bwd: bad qkv layout %d", qkv_layout);
     const int rows = B * N, I = H * DH;
     char* ws = (char*)workspace;
     void* dout = ws;
     void* dqkv = ws + align256((long long)rows * I * esize(dt));
     void* dxn = (char*)dqkv + align256((long long)rows * 3 * I * esize(dt));
     void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
+    // dqkv lives in the workspace, so its layout is this call's own choice: planes when the three consumers below can
+    // read them (a qkv bias wants the column sums of the row-major matrix; the input gradient wants the transposed weight)
+    const bool dq_planes = (g_qkv_planes & 2) && !db_qkv && w_qkv_t && vitmi_qkv_planes_ok(dt, B, N, D, H, DH, xn, w_qkv_t, dqkv);
     STEP(input_grad(dt, rows, I, D, dy, w_out, w_out_t, dout, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
-    STEP(vitmi_attn_bwd(qkv, o, dout, lse, nullptr, dqkv, scratch, dt, B, N, H, DH, stream));
+    STEP(vitmi_attn_bwd(qkv, o, dout, lse, nullptr, dqkv, scratch, dt, B, N, H, DH,
+                        qkv_layout | (dq_planes ? VITMI_DQKV_HEAD_MAJOR : 0), stream));
+    if (dq_planes) {
+        STEP(vitmi_gemm_wgrad_pair_planes(rows, D, I, dy, D, o, I, dw_out, 3 * I, D, dqkv, xn, D, dw_qkv, scratch, stream));
+        STEP(vitmi_gemm_from_planes(rows, D, 3 * I, dqkv, w_qkv_t, dxn, stream));
+        STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db_out, scratch, dt, rows, D, stream));
+        return VITMI_OK;
+    }
     STEP(vitmi_gemm_wgrad_pair(dt, rows, D, I, dy, D, o, I, dw_out, 3 * I, D, dqkv, 3 * I, xn, D, dw_qkv, scratch, stream));
     if (db_qkv) STEP(vitmi_colsum(dqkv, dt, rows, 3 * I, 3 * I, db_qkv, scratch, stream));
     STEP(input_grad(dt, rows, D, 3 * I, dqkv, w_qkv, w_qkv_t, dxn, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
@@ -166,7 +208,7 @@ extern "C" int vitmi_attn_block_infer(int B, int N, int D, int H, int DH, const 
     float* lse = (float*)((char*)o + align256((long long)rows * I * 2));
     STEP(vitmi_row_stats(x, D, mean, rstd, VITMI_BF16, rows, D, eps, stream));
     STEP(vitmi_gemm_ln(rows, 3 * I, D, x, D, wq_folded, bq_folded, wq_rowsum, mean, rstd, qkv, 3 * I, VITMI_EPI_LN, stream));
-    STEP(vitmi_attn_fwd(qkv, o, lse, probs, VITMI_BF16, B, N, H, DH, stream));
+    STEP(vitmi_attn_fwd(qkv, o, lse, probs, VITMI_BF16, B, N, H, DH, 0, stream));
     STEP(vitmi_gemm(VITMI_BF16, rows, D, I, o, I, 1, w_out, I, 1, y, D, VITMI_BF16, VITMI_EPI_NONE, b_out, x, D, nullptr, 0,
                     stream));
     return VITMI_OK;

@@ -37,7 +37,12 @@ int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const 
 long long vitmi_gemm_tn_batch_bytes(int n, const int* P, const int* Q, int T);
 long long vitmi_gemm_tn_batch_bytes_bound(int n, const int* P, const int* Q, int T);
 int vitmi_gemm_tn_batch(int n, const int* P, const int* Q, int T, const void* const* U, const long long* ldu,
-                        const void* const* V, const long long* ldv, float* const* C, float* partial, hipStream_t s);
+                        const void* const* V, const long long* ldv, float* const* C, float* partial, hipStream_t s,
+                        const int* u_planes);
+int vitmi_gemm_tn_fast_planes(int P, int Q, int T, const void* U, const void* V, long long ldv, float* C, long long ldc,
+                              float* slabs, hipStream_t s);
+int vitmi_gemm_nt_fast_planes(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
+                              long long ldc, const float* bias, int out_planes, int a_planes, hipStream_t s);
 bool vitmi_patch_fast_ok(const void* img, const void* w, const void* out, int W, int p, int D, int E,
                          long long out_batch_stride);
 int vitmi_patch_fwd_fast(const void* img, const void* w, const float* bias, void* out, int B, int C, int H, int W,
@@ -627,10 +632,59 @@ extern "C" int vitmi_gemm_wgrad_pair(int dt, int T, int P0, int Q0, const void* 
         const long long ldu[2] = {ldu0, ldu1}, ldv[2] = {ldv0, ldv1};
         float* C[2] = {C0, C1};
         ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * ((double)P0 * Q0 + (double)P1 * Q1) * (double)T);
-        const int rc = vitmi_gemm_tn_batch(2, P, Q, T, U, ldu, V, ldv, C, (float*)workspace, s);
+        const int rc = vitmi_gemm_tn_batch(2, P, Q, T, U, ldu, V, ldv, C, (float*)workspace, s, nullptr);
         if (rc != VITMI_ERR_UNSUPPORTED) return rc;
     }
     const int rc = vitmi_gemm_wgrad(dt, P0, Q0, T, U0, ldu0, V0, ldv0, C0, Q0, workspace, stream);
     if (rc != VITMI_OK) return rc;
     return vitmi_gemm_wgrad(dt, P1, Q1, T, U1, ldu1, V1, ldv1, C1, Q1, workspace, stream);
+}
+
+// ---- the products around the attention core when qkv / dqkv are head-major planes [3*H][tokens][64] (bf16, heads of 64;
+// chosen by the whole-block entry points of blocks.hip, which also own the decision that every operand qualifies)
+bool vitmi_qkv_planes_ok(int dt, int B, int N, int D, int H, int DH, const void* x, const void* w_qkv, const void* qkv) {
+    (void)B;
+    (void)N;
+    (void)H;
+    return dt == VITMI_BF16 && DH == 64 && D % 8 == 0 && al16(x) && al16(w_qkv) && al16(qkv);
+}
+
+// qkv planes = xn W^T (+ bias)
+int vitmi_gemm_to_planes(int T, int N, int K, const void* xn, const void* w, const float* bias, void* planes, void* stream) {
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_GEMM_NT_FAST0, s, 2.0 * T * N * K);
+    return vitmi_gemm_nt_fast_planes(T, N, K, xn, K, w, K, planes, N, bias, 1, 0, s);
+}
+
+// dxn = dqkv W for dqkv in planes: the k-contiguous form on the transposed weight w_t [K_out = D][3I]
+int vitmi_gemm_from_planes(int T, int D, int I3, const void* dqkv_planes, const void* w_t, void* dxn, void* stream) {
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_GEMM_NT_FAST0, s, 2.0 * T * D * I3);
+    return vitmi_gemm_nt_fast_planes(T, D, I3, dqkv_planes, 64, w_t, I3, dxn, D, nullptr, 0, 1, s);
+}
+
+// the two weight gradients of the attention sub-block with the second product's dy (dqkv) in planes
+int vitmi_gemm_wgrad_pair_planes(int T, int P0, int Q0, const void* U0, long long ldu0, const void* V0, long long ldv0,
+                                 float* C0, int P1, int Q1, const void* U1_planes, const void* V1, long long ldv1, float* C1,
+                                 void* workspace, void* stream) {
+    hipStream_t s = as_stream(stream);
+    const int P[2] = {P0, P1}, Q[2] = {Q0, Q1};
+    if (workspace && vitmi_gemm_tn_batch_bytes(2, P, Q, T) > 0) {
+        const void* U[2] = {U0, U1_planes};
+        const void* V[2] = {V0, V1};
+        const long long ldu[2] = {ldu0, 64}, ldv[2] = {ldv0, ldv1};
+        const int planes[2] = {0, 1};
+        float* C[2] = {C0, C1};
+        ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * ((double)P0 * Q0 + (double)P1 * Q1) * (double)T);
+        const int rc = vitmi_gemm_tn_batch(2, P, Q, T, U, ldu, V, ldv, C, (float*)workspace, s, planes);
+        if (rc != VITMI_ERR_UNSUPPORTED) return rc;
+    }
+    int rc = vitmi_gemm_wgrad(VITMI_BF16, P0, Q0, T, U0, ldu0, V0, ldv0, C0, Q0, workspace, stream);
+    if (rc != VITMI_OK) return rc;
+    if (!vitmi_gemm_tn_fast_ok(P1, Q1, U1_planes, 64, V1, ldv1, C1, Q1)) {
+        vitmi_set_error("weight gradient from head-major planes: operands must be 16-byte aligned with extents multiples of 8");
+        return VITMI_ERR_UNSUPPORTED;
+    }
+    ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * P1 * Q1 * (double)T);
+    return vitmi_gemm_tn_fast_planes(P1, Q1, T, U1_planes, V1, ldv1, C1, Q1, (float*)workspace, s);
 }

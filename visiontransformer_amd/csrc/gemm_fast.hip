@@ -42,9 +42,11 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 __device__ __forceinline__ int swz_nt(int row) { return (row & 7) ^ (((row >> 4) & 1) << 2); }
 
 // stage one [ROWS][64 k] tile with NW waves: wave w issues ROWS/8/NW loads, each covering 8 rows
+// kstep: elements between the 64-wide k-blocks of a row.  64 (= TK) for an ordinary row-major operand; for the
+// head-major planes of dqkv ([3*H][tokens][64], ld = 64) it is tokens * 64: k-block j of row m lives in plane j
 template <int ROWS, int NW>
 __device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ g, long long ld, int row0, int rows, int k0, int K,
-                                         bf16_t* lds, int wave, int lane) {
+                                         bf16_t* lds, int wave, int lane, long long kstep = TK) {
     constexpr int PER = ROWS / 8 / NW;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -52,7 +54,8 @@ __device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ g, long long
         const int r = rblk + (lane >> 3);
         const int c = (lane & 7) ^ swz_nt(r);      // logical chunk this lane fetches
         const int gr = row0 + r, gk = k0 + c * 8;
-        const void* src = (gr < rows && gk < K) ? (const void*)(g + (long long)gr * ld + gk) : (const void*)g_zero16;
+        const void* src = (gr < rows && gk < K) ? (const void*)(g + (long long)gr * ld + (long long)(gk >> 6) * kstep + (gk & 63))
+                                                : (const void*)g_zero16;
         glds16(src, lds + rblk * TK);
     }
 }
@@ -108,7 +111,20 @@ struct FastEpi {
     const float* ln_mean;
     const float* ln_rstd;
     const float* ln_s;
+    // > 0: C is written as head-major planes [N / 64][hm_T rows][64] (hm_T = M): column block j of row m at
+    // C + (j * hm_T + m) * 64.  The layout the attention kernels read qkv in for heads of 64.
+    long long hm_T;
+    long long a_kstep;       // see stage_nt: elements between the 64-wide k-blocks of an A row (0 = contiguous rows)
 };
+template <typename OutT>
+__device__ __forceinline__ OutT* epi_out_ptr(const FastEpi& e, int m, int n) {
+    if (e.hm_T > 0) return reinterpret_cast<OutT*>(e.C) + ((long long)(n >> 6) * e.hm_T + m) * 64 + (n & 63);
+    if (e.rows_per_group > 0) {
+        const int gi = m / e.rows_per_group;
+        return reinterpret_cast<OutT*>(e.C) + (long long)gi * e.group_stride + (long long)(m - gi * e.rows_per_group) * e.ldc + n;
+    }
+    return reinterpret_cast<OutT*>(e.C) + (long long)m * e.ldc + n;
+}
 
 // v[t] belongs to row m, column n + (t & 7) + (t >> 3) * H2: two runs of 8 consecutive columns, H2
 // apart (H2 = 8: one run of 16)
@@ -197,12 +213,7 @@ __device__ __forceinline__ void epi_row16(const FastEpi& e, int m, int n, int N,
                 if (col(t) < N) v[t] += (float)r[col(t) - n];
         }
     }
-    OutT* c = reinterpret_cast<OutT*>(e.C) + (long long)m * e.ldc + n;
-    if (e.rows_per_group > 0) {
-        const int gi = m / e.rows_per_group;
-        c = reinterpret_cast<OutT*>(e.C) + (long long)gi * e.group_stride +
-            (long long)(m - gi * e.rows_per_group) * e.ldc + n;
-    }
+    OutT* c = epi_out_ptr<OutT>(e, m, n);
     if (full) {
         if (sizeof(OutT) == 2) {
             bf16x8 p0, p1;
@@ -331,7 +342,7 @@ __device__ __forceinline__ void epi_subtile_fast(const FastEpi& e, f32x4 (&acc)[
                 p0[t] = (bf16_t)v[t];
                 p1[t] = (bf16_t)v[8 + t];
             }
-            bf16_t* c = reinterpret_cast<bf16_t*>(e.C) + (long long)m * e.ldc + n;
+            bf16_t* c = epi_out_ptr<bf16_t>(e, m, n);
             *reinterpret_cast<bf16x8*>(c) = p0;
             *reinterpret_cast<bf16x8*>(c + 32) = p1;
             if (CS) {
@@ -386,10 +397,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(const bf16_t
     // before the MFMAs of tile kt and drained by the barrier's wait.  (A hand-pipelined variant with
     // two register fragment sets measured 10-25 % slower: it spills and defeats hipcc's own
     // interleave of ds_read and MFMA.)
+    const long long a_kstep = epi.a_kstep > 0 ? epi.a_kstep : TK;
     if (PATCH)
         stage_nt_patch<BM, NW>(A, pg, m0, 0, smem, wave, lane);
     else
-        stage_nt<BM, NW>(A, lda, m0, M, 0, K, smem, wave, lane);
+        stage_nt<BM, NW>(A, lda, m0, M, 0, K, smem, wave, lane, a_kstep);
     stage_nt<BN, NW>(B, ldb, n0, N, 0, K, smem + BM * TK, wave, lane);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_fast_kernel(const bf16_t
             if (PATCH)
                 stage_nt_patch<BM, NW>(A, pg, m0, (kt + 1) * TK, An, wave, lane);
             else
-                stage_nt<BM, NW>(A, lda, m0, M, (kt + 1) * TK, K, An, wave, lane);
+                stage_nt<BM, NW>(A, lda, m0, M, (kt + 1) * TK, K, An, wave, lane, a_kstep);
             stage_nt<BN, NW>(B, ldb, n0, N, (kt + 1) * TK, K, An + BM * TK, wave, lane);
         }
 #pragma unroll
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __res
     // per-lane source of load i of the next region of kind s (0 RA0, 1 RB0, 2 RB1, 3 RA1); rows
     // past the edge read the zero word and do not advance.
     const char* src[4][2];
-    int inc[4][2];
+    long long inc[4][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int rho = (wave * 2 + i) * 8 + (lane >> 3);  // row inside the region
@@ -527,7 +539,7 @@ __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __res
             const bool ok = g < (isA ? M : N);
             const bf16_t* base = isA ? A + (long long)g * lda : B + (long long)g * ldb;
             src[s4][i] = ok ? (const char*)(base + c * 8) : (const char*)g_zero16;
-            inc[s4][i] = ok ? TK * 2 : 0;
+            inc[s4][i] = ok ? ((isA && epi.a_kstep > 0) ? epi.a_kstep * 2 : (long long)TK * 2) : 0;
         }
     }
     // issue region h of the stream (kind h & 3 of K-tile h >> 2); regions go out strictly in order
@@ -738,9 +750,11 @@ __global__ __launch_bounds__(512) void gemm_nt_phased_kernel(const bf16_t* __res
 __device__ __forceinline__ int swz_tn(int t) { return ((t & 3) | (((t >> 3) & 1) << 2)) << 1; }
 
 // stage one [64 t][COLS] tile with NW waves: one load = 1 KiB = 512/COLS rows
+// plane: 0 for a row-major operand; for head-major planes [cols / 64][tokens][64] (ld = 64) the elements of one
+// plane, tokens * 64: column block j of token t lives at g + j * plane + t * 64
 template <int COLS, int NW>
 __device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ g, long long ld, int t0, int T, int col0, int cols,
-                                         bf16_t* lds, int wave, int lane) {
+                                         bf16_t* lds, int wave, int lane, long long plane = 0) {
     constexpr int CPR = COLS / 8;          // 16-byte chunks per row
     constexpr int RPI = 64 / CPR;          // rows per load instruction
     constexpr int PER = (64 / RPI) / NW;   // loads per wave
@@ -750,7 +764,8 @@ __device__ __forceinline__ void stage_tn(const bf16_t* __restrict__ g, long long
         const int t = tblk + lane / CPR;
         const int c = (lane % CPR) ^ swz_tn(t);
         const int gt = t0 + t, gc = col0 + c * 8;
-        const void* src = (gt < T && gc < cols) ? (const void*)(g + (long long)gt * ld + gc) : (const void*)g_zero16;
+        const long long off = plane > 0 ? (long long)(gc >> 6) * plane + (long long)gt * 64 + (gc & 63) : (long long)gt * ld + gc;
+        const void* src = (gt < T && gc < cols) ? (const void*)(g + off) : (const void*)g_zero16;
         glds16(src, lds + tblk * COLS);
     }
 }
@@ -804,7 +819,7 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
                                                                     float* __restrict__ C, long long ldc,
                                                                     long long slab_stride, int P, int Q, int T,
                                                                     int tiles_q, int tiles_pq, int kt_per_slab,
-                                                                    PatchGeom pg) {
+                                                                    PatchGeom pg, long long u_plane) {
     constexpr int NW = WP * WQ, WTP = BP / WP, WTQ = BQ / WQ, MI = WTP / 16, NJ = WTQ / 16;
     constexpr int STAGE = TK * (BP + BQ);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -856,7 +871,7 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
         auto stage = [&](int it, bf16_t* dst) {
             const int sg = s_lo + it / ktps, kt = it % ktps;
             const int tb = sg * seglen, tl = min(T, tb + seglen);
-            stage_tn<BP, NW>(U, ldu, tb + kt * TK, tl, p0, P, dst, wave, lane);
+            stage_tn<BP, NW>(U, ldu, tb + kt * TK, tl, p0, P, dst, wave, lane, u_plane);
             stage_tn<BQ, NW>(V, ldv, tb + kt * TK, tl, q0, Q, dst + TK * BP, wave, lane);
         };
         if (n_it > 0) stage(0, smem);
@@ -895,7 +910,7 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
     const int kt_begin = slab * kt_per_slab;
     const int kt_end = min(kt_begin + kt_per_slab, nk_all);
     if (kt_begin < kt_end) {
-        stage_tn<BP, NW>(U, ldu, kt_begin * TK, T, p0, P, smem, wave, lane);
+        stage_tn<BP, NW>(U, ldu, kt_begin * TK, T, p0, P, smem, wave, lane, u_plane);
         if (PATCH)
             stage_tn_patch<BQ, NW>(V, pg, kt_begin * TK, q0, smem + TK * BP, wave, lane);
         else
@@ -908,7 +923,7 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
         bf16_t* Vs = Us + TK * BP;
         if (kt + 1 < kt_end) {
             bf16_t* Un = smem + (b ^ 1) * STAGE;
-            stage_tn<BP, NW>(U, ldu, (kt + 1) * TK, T, p0, P, Un, wave, lane);
+            stage_tn<BP, NW>(U, ldu, (kt + 1) * TK, T, p0, P, Un, wave, lane, u_plane);
             if (PATCH)
                 stage_tn_patch<BQ, NW>(V, pg, (kt + 1) * TK, q0, Un + TK * BP, wave, lane);
             else
@@ -961,7 +976,7 @@ __device__ __forceinline__ u32x2 tr_read(unsigned lds_addr) {
 __device__ __forceinline__ void tn_phased_tile(const bf16_t* __restrict__ U, long long ldu,
                                                const bf16_t* __restrict__ V, long long ldv, int P, int Q, int p0,
                                                int q0, int kt_begin, int kt_end, float* __restrict__ out,
-                                               long long ldo, unsigned char* smem_raw) {
+                                               long long ldo, unsigned char* smem_raw, long long u_plane = 0) {
     constexpr int RGT = TK * 128;  // elements per region: 64 t x 128 columns
     bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
     typedef __attribute__((address_space(3))) unsigned char* lds_u8p;
@@ -987,8 +1002,10 @@ __device__ __forceinline__ void tn_phased_tile(const bf16_t* __restrict__ U, lon
             const bool isU = (s4 == 0 || s4 == 3);
             const int g = (isU ? p0 : q0) + cols[s4];
             const bool ok = g < (isU ? P : Q);
-            const long long ld = isU ? ldu : ldv;
-            const bf16_t* base = (isU ? U : V) + ((long long)kt_begin * TK + tl) * ld + g;
+            const bool planes = isU && u_plane > 0;     // U as head-major planes [P / 64][tokens][64]
+            const long long ld = planes ? 64 : (isU ? ldu : ldv);
+            const bf16_t* base = (isU ? U : V) + ((long long)kt_begin * TK + tl) * ld +
+                                 (planes ? (long long)(g >> 6) * u_plane + (g & 63) : (long long)g);
             src[s4][i] = ok ? (const char*)base : (const char*)g_zero16;
             inc[s4][i] = ok ? ld * TK * 2 : 0;
         }
@@ -1151,14 +1168,14 @@ __global__ __launch_bounds__(512) void gemm_tn_phased_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ V, long long ldv,
                                                              float* __restrict__ C, long long ldc,
                                                              long long slab_stride, int P, int Q, int tiles_q,
-                                                             int tiles_pq, int kt_per_slab, int nk_all) {
+                                                             int tiles_pq, int kt_per_slab, int nk_all, long long u_plane) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lin = xcd_remap(blockIdx.x, gridDim.x);
     const int slab = lin / tiles_pq, tile = lin - slab * tiles_pq;
     const int p0 = (tile / tiles_q) * 256, q0 = (tile % tiles_q) * 256;
     const int kt_begin = slab * kt_per_slab;
     const int kt_end = min(kt_begin + kt_per_slab, nk_all);
-    tn_phased_tile(U, ldu, V, ldv, P, Q, p0, q0, kt_begin, kt_end, C + (long long)slab * slab_stride, ldc, smem_raw);
+    tn_phased_tile(U, ldu, V, ldv, P, Q, p0, q0, kt_begin, kt_end, C + (long long)slab * slab_stride, ldc, smem_raw, u_plane);
 }
 
 // Several weight gradients over the SAME token axis in one launch that fills the chip once (each product alone
@@ -1174,6 +1191,7 @@ struct TnBatchProblem {
     const bf16_t* V;
     float* C;
     long long ldu, ldv, ldc;
+    long long u_plane;       // > 0: U is head-major planes [P / 64][tokens][64], this many elements per plane
     int Q, tiles_q, tile_begin, pad;
 };
 struct TnBatch {
@@ -1231,7 +1249,7 @@ __global__ __launch_bounds__(512) void gemm_tn_batch_kernel(const TnBatch tb) {
         const int lt = tile - pr.tile_begin;
         const int p0 = (lt / pr.tiles_q) * 256, q0 = (lt % pr.tiles_q) * 256;
         float* out = tb.partial + (long long)slot * TN_SLOT - ((long long)p0 * 256 + q0);
-        tn_phased_tile(pr.U, pr.ldu, pr.V, pr.ldv, 1 << 30, 1 << 30, p0, q0, kb, ke, out, 256, smem_raw);
+        tn_phased_tile(pr.U, pr.ldu, pr.V, pr.ldv, 1 << 30, 1 << 30, p0, q0, kb, ke, out, 256, smem_raw, pr.u_plane);
         if (is_main) break;
     }
 }
@@ -1484,12 +1502,14 @@ static int launch_nt_epi(int M, int N, int K, const bf16_t* a, long long lda, co
                     int rc = launch_nt_phased<EPI, OutT>(M1, N, K, a, lda, b, ldb, e, s);
                     if (rc != VITMI_OK) return rc;
                     FastEpi t = e;
-                    t.C = reinterpret_cast<OutT*>(e.C) + (long long)M1 * e.ldc;
+                    // head-major planes: the rows of the tail start M1 * 64 elements into every plane, the plane
+                    // stride stays that of the whole matrix
+                    t.C = reinterpret_cast<OutT*>(e.C) + (long long)M1 * (e.hm_T > 0 ? 64 : e.ldc);
                     if (e.res) t.res = e.res + (long long)M1 * e.ldr;
                     if (e.aux) t.aux = e.aux + (long long)M1 * e.ldaux;
                     if (e.ln_mean) t.ln_mean = e.ln_mean + M1, t.ln_rstd = e.ln_rstd + M1;
                     return launch_nt_cfg<EPI, OutT, PATCH, 128, 128, 2, 2>(M - M1, N, K, a + (long long)M1 * lda, lda, b, ldb,
-                                                                         t, pg, s);
+                                                                         t, pg, s);   // (lda = 64 for a head-major A)
                 }
                 return launch_nt_phased<EPI, OutT>(M, N, K, a, lda, b, ldb, e, s);
             }
@@ -1534,8 +1554,19 @@ int vitmi_gemm_nt_colsum_rows(int M) { return 2 * ceil_div(M, 256); }
 int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
                        long long ldc, int c_dt, int epilogue, const float* bias, const void* residual, long long ldr,
                        void* aux, long long ldaux, float* cs_partial, hipStream_t s) {
-    FastEpi e{C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)aux, ldaux, 0, 0, cs_partial, nullptr, nullptr, nullptr};
+    FastEpi e{C, ldc, bias, (const bf16_t*)residual, ldr, (bf16_t*)aux, ldaux, 0, 0, cs_partial, nullptr, nullptr, nullptr, 0, 0};
     return launch_nt_fast<false>(M, N, K, A, lda, B, ldb, e, c_dt, epilogue, PatchGeom{}, s);
+}
+
+// The two products around the attention core with qkv / dqkv as head-major planes [3*H][tokens][64] (bf16, plain
+// epilogue, every extent a multiple of 8, N resp. K a multiple of 64):
+//   out_planes: C = A B^T + bias written as planes (the qkv projection; N = 3*H*64, tokens = M)
+//   a_planes:   A is read from planes (the input gradient behind dqkv; K = 3*H*64, tokens = M), C row-major
+int vitmi_gemm_nt_fast_planes(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
+                              long long ldc, const float* bias, int out_planes, int a_planes, hipStream_t s) {
+    FastEpi e{C, ldc, bias, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr, out_planes ? (long long)M : 0,
+              a_planes ? (long long)M * 64 : 0};
+    return launch_nt_fast<false>(M, N, K, A, a_planes ? 64 : lda, B, ldb, e, VITMI_BF16, VITMI_EPI_NONE, PatchGeom{}, s);
 }
 
 // C (bf16) = epilogue(LayerNorm(x) W^T + b) without the normalised rows ever being formed: A = x, B = the weight
@@ -1543,7 +1574,7 @@ int vitmi_gemm_nt_fast(int M, int N, int K, const void* A, long long lda, const 
 int vitmi_gemm_nt_fast_ln(int M, int N, int K, const void* A, long long lda, const void* B, long long ldb, void* C,
                           long long ldc, int epilogue, const float* bias, const float* ln_mean, const float* ln_rstd,
                           const float* ln_s, hipStream_t s) {
-    FastEpi e{C, ldc, bias, nullptr, 0, nullptr, 0, 0, 0, nullptr, ln_mean, ln_rstd, ln_s};
+    FastEpi e{C, ldc, bias, nullptr, 0, nullptr, 0, 0, 0, nullptr, ln_mean, ln_rstd, ln_s, 0, 0};
     return launch_nt_fast<false>(M, N, K, A, lda, B, ldb, e, VITMI_BF16, epilogue, PatchGeom{}, s);
 }
 
@@ -1559,7 +1590,7 @@ int vitmi_patch_fwd_fast(const void* img, const void* w, const float* bias, void
                          int p, int D, long long out_batch_stride, hipStream_t s) {
     const int gh = H / p, gw = W / p, per = gh * gw, E = C * p * p;
     PatchGeom pg{C, H, W, p, gw, per, B * per, E};
-    FastEpi e{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride, nullptr, nullptr, nullptr, nullptr};
+    FastEpi e{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride, nullptr, nullptr, nullptr, nullptr, 0, 0};
     return launch_nt_fast<true>(B * per, D, E, img, 0, w, E, e, VITMI_BF16, VITMI_EPI_NONE, pg, s);
 }
 
@@ -1612,7 +1643,7 @@ int vitmi_gemm_tn_slabs_bound(int P, int Q, int T) {
 
 template <bool PATCH, int BP, int BQ, int WP, int WQ>
 static int launch_tn_cfg(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
-                         long long ldc, float* slabs, int ns, const PatchGeom& pg, hipStream_t s) {
+                         long long ldc, float* slabs, int ns, const PatchGeom& pg, hipStream_t s, long long u_plane = 0) {
     static unsigned long long done = 0;
     constexpr size_t lds = 2 * (size_t)TK * (BP + BQ) * sizeof(bf16_t);
     auto fn = gemm_tn_fast_kernel<PATCH, BP, BQ, WP, WQ>;
@@ -1626,14 +1657,14 @@ static int launch_tn_cfg(int P, int Q, int T, const void* U, long long ldu, cons
     dim3 grid(tiles_p * tiles_q * ns), block(64 * WP * WQ);
     if (ns == 1) {
         hipLaunchKernelGGL(fn, grid, block, lds, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv, C, ldc, 0ll, P, Q, T,
-                           tiles_q, tiles_p * tiles_q, per, pg);
+                           tiles_q, tiles_p * tiles_q, per, pg, u_plane);
         VITMI_LAUNCH_CHECK("vitmi_gemm(tn fast)");
         return VITMI_OK;
     }
     // slabs are dense [ns][P][ldc] so that the reduce is a flat sum when C is dense
     const long long slab_stride = (long long)P * ldc;
     hipLaunchKernelGGL(fn, grid, block, lds, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv, slabs, ldc, slab_stride,
-                       P, Q, T, tiles_q, tiles_p * tiles_q, per, pg);
+                       P, Q, T, tiles_q, tiles_p * tiles_q, per, pg, u_plane);
     VITMI_LAUNCH_CHECK("vitmi_gemm(tn fast)");
     const long long n4 = slab_stride / 4;
     int blocks = (int)std::min<long long>((n4 + 255) / 256, 2048);
@@ -1643,7 +1674,7 @@ static int launch_tn_cfg(int P, int Q, int T, const void* U, long long ldu, cons
 }
 
 static int launch_tn_phased(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
-                            long long ldc, float* slabs, int ns, hipStream_t s) {
+                            long long ldc, float* slabs, int ns, hipStream_t s, long long u_plane = 0) {
     static unsigned long long done = 0;
     constexpr size_t lds = 2 * 4 * (size_t)TK * 128 * sizeof(bf16_t);
     int rc = ensure_lds_attr(reinterpret_cast<const void*>(gemm_tn_phased_kernel), lds, &done);
@@ -1657,7 +1688,7 @@ static int launch_tn_phased(int P, int Q, int T, const void* U, long long ldu, c
     const bool direct = (ns == 1);
     const long long slab_stride = direct ? 0ll : (long long)P * ldc;
     hipLaunchKernelGGL(gemm_tn_phased_kernel, grid, block, lds, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
-                       direct ? C : slabs, ldc, slab_stride, P, Q, tiles_q, tiles_p * tiles_q, per, nk);
+                       direct ? C : slabs, ldc, slab_stride, P, Q, tiles_q, tiles_p * tiles_q, per, nk, u_plane);
     VITMI_LAUNCH_CHECK("vitmi_gemm(tn phased)");
     if (!direct) {
         const long long n4 = slab_stride / 4;
@@ -1670,13 +1701,13 @@ static int launch_tn_phased(int P, int Q, int T, const void* U, long long ldu, c
 
 template <bool PATCH>
 static int launch_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
-                          long long ldc, float* slabs, const PatchGeom& pg, hipStream_t s) {
+                          long long ldc, float* slabs, const PatchGeom& pg, hipStream_t s, long long u_plane = 0) {
     const int ns = vitmi_gemm_tn_slabs(P, Q, T);
     if (!PATCH && pick_tn_cfg(P, Q) == 2 && T % TK == 0 && T > 0)
-        return launch_tn_phased(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, s);
+        return launch_tn_phased(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, s, u_plane);
     if (pick_tn_cfg(P, Q) >= 1)
-        return launch_tn_cfg<PATCH, 256, 256, 2, 4>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s);
-    return launch_tn_cfg<PATCH, 128, 128, 2, 2>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s);
+        return launch_tn_cfg<PATCH, 256, 256, 2, 4>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s, u_plane);
+    return launch_tn_cfg<PATCH, 128, 128, 2, 2>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s, u_plane);
 }
 
 // per-segment tile sums of squares: partial[seg][tile]; returns the number of tiles per segment through *tiles
@@ -1696,7 +1727,7 @@ static int launch_tn_seg(int P, int Q, int T, int seg, const void* U, long long 
     const int per = ceil_div(nseg, want < 1 ? 1 : want);
     const int groups = ceil_div(nseg, per);
     hipLaunchKernelGGL(fn, dim3(ntiles * groups), dim3(64 * WP * WQ), lds, s, (const bf16_t*)U, ldu, (const bf16_t*)V, ldv,
-                       partial, 0ll, 0ll, P, Q, T, tiles_q, ntiles, seg, PatchGeom{});
+                       partial, 0ll, 0ll, P, Q, T, tiles_q, ntiles, seg, PatchGeom{}, 0ll);
     VITMI_LAUNCH_CHECK("vitmi_gemm_wgrad_sqnorm(tn segments)");
     return VITMI_OK;
 }
@@ -1713,6 +1744,11 @@ int vitmi_gemm_tn_seg_sq(int P, int Q, int T, int seg, const void* U, long long 
 int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,
                        long long ldc, float* slabs, hipStream_t s) {
     return launch_tn_fast<false>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, PatchGeom{}, s);
+}
+// the same with U as head-major planes [P / 64][T][64] (P a multiple of 64)
+int vitmi_gemm_tn_fast_planes(int P, int Q, int T, const void* U, const void* V, long long ldv, float* C, long long ldc,
+                              float* slabs, hipStream_t s) {
+    return launch_tn_fast<false>(P, Q, T, U, 64, V, ldv, C, ldc, slabs, PatchGeom{}, s, (long long)T * 64);
 }
 
 // ---- several weight gradients over one token axis in one launch (gemm_tn_batch_kernel)
@@ -1791,11 +1827,13 @@ long long vitmi_gemm_tn_batch_bytes_bound(int n, const int* P, const int* Q, int
 // C[i] (dense [P[i]][Q[i]] fp32) = U[i]^T V[i] over T tokens for i < n; VITMI_ERR_UNSUPPORTED when the shapes do
 // not qualify
 int vitmi_gemm_tn_batch(int n, const int* P, const int* Q, int T, const void* const* U, const long long* ldu,
-                        const void* const* V, const long long* ldv, float* const* C, float* partial, hipStream_t s) {
+                        const void* const* V, const long long* ldv, float* const* C, float* partial, hipStream_t s,
+                        const int* u_planes) {
     TnBatch tb;
     if (!partial || !tn_batch_plan(n, P, Q, T, &tb)) return VITMI_ERR_UNSUPPORTED;
     for (int i = 0; i < n; ++i) {
         if (!vitmi_gemm_tn_fast_ok(P[i], Q[i], U[i], ldu[i], V[i], ldv[i], C[i], Q[i])) return VITMI_ERR_UNSUPPORTED;
+        tb.pr[i].u_plane = (u_planes && u_planes[i]) ? (long long)T * 64 : 0;
         tb.pr[i].U = (const bf16_t*)U[i];
         tb.pr[i].V = (const bf16_t*)V[i];
         tb.pr[i].C = C[i];

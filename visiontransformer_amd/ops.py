@@ -372,20 +372,25 @@ def layernorm_bwd(dy2, x2, gamma, mean, rstd, dres=None, need_affine=True, want_
     return dx, dg, db
 
 
-def attn_fwd(qkv, B, N, H, DH, want_probs):
+QKV_HEAD_MAJOR = 1      # qkv stored as planes [3][H][B*N][DH] (what the whole-block forward leaves for bf16 heads of 64)
+
+
+def attn_fwd(qkv, B, N, H, DH, want_probs, layout=0):
     I = H * DH
     out = torch.empty((B, N, I), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
     probs = torch.empty((B, H, N, N), dtype=qkv.dtype, device=qkv.device) if want_probs else None
-    check(lib.vitmi_attn_fwd(_p(qkv), _p(out), _p(lse), _p(probs), _dt(qkv), B, N, H, DH, _stream()), "vitmi_attn_fwd")
+    check(lib.vitmi_attn_fwd(_p(qkv), _p(out), _p(lse), _p(probs), _dt(qkv), B, N, H, DH, layout, _stream()),
+          "vitmi_attn_fwd")
     return out, lse, probs
 
 
-def attn_bwd(qkv, out, dout, lse, B, N, H, DH):
+def attn_bwd(qkv, out, dout, lse, B, N, H, DH, layout=0):
+    """dqkv [B,N,3*H*DH] in the row layout of to_qkv's output; `layout` says how the saved qkv is stored."""
     dqkv = torch.empty_like(qkv)
     ws = _ws(lib.vitmi_attn_bwd_workspace_bytes(_dt(qkv), B, N, H, DH), qkv.device)
     check(lib.vitmi_attn_bwd(_p(qkv), _p(out), _p(dout), _p(lse), None, _p(dqkv), _p(ws), _dt(qkv), B, N, H, DH,
-                             _stream()), "vitmi_attn_bwd")
+                             layout & QKV_HEAD_MAJOR, _stream()), "vitmi_attn_bwd")
     return dqkv
 
 
@@ -396,7 +401,7 @@ def attn_bwd_dprobs(qkv, lse, dprobs, B, N, H, DH):
         dprobs = cast(dprobs, qkv.dtype)
     dqkv = torch.empty_like(qkv)
     ws = _ws(lib.vitmi_attn_bwd_dprobs_workspace_bytes(_dt(qkv), B, N, H, DH), qkv.device)
-    check(lib.vitmi_attn_bwd(_p(qkv), None, None, _p(lse), _p(dprobs), _p(dqkv), _p(ws), _dt(qkv), B, N, H, DH,
+    check(lib.vitmi_attn_bwd(_p(qkv), None, None, _p(lse), _p(dprobs), _p(dqkv), _p(ws), _dt(qkv), B, N, H, DH, 0,
                              _stream()), "vitmi_attn_bwd(dprobs)")
     return dqkv
 
@@ -1005,12 +1010,13 @@ class AttnBlockFn(_BlockFn):
             lse = torch.empty((B, heads, N), dtype=f32, device=dev)
             probs = torch.empty((B, heads, N, N), dtype=cdt, device=dev) if want_probs else None
             y = torch.empty((rows, D), dtype=cdt, device=dev)
+            qkv_layout = int(lib.vitmi_attn_block_qkv_layout(_dt(cdt), B, N, D, heads, dh))
             check(lib.vitmi_attn_block_fwd(_dt(cdt), B, N, D, heads, dh, _p(x2), _p(g), _p(ln_b.detach().float()), eps,
                                            _p(compute_copy(w_qkv, cdt)),
                                            _p(b_qkv.detach().float()) if b_qkv is not None else None,
                                            _p(compute_copy(w_out, cdt)),
                                            _p(b_out.detach().float()) if b_out is not None else None, _p(xn), _p(mean),
-                                           _p(rstd), _p(qkv), _p(o), _p(lse), _p(probs), _p(y), _stream()),
+                                           _p(rstd), _p(qkv), _p(o), _p(lse), _p(probs), _p(y), qkv_layout, _stream()),
                   "vitmi_attn_block_fwd")
         else:
             if ln_w is not None:
@@ -1030,6 +1036,7 @@ class AttnBlockFn(_BlockFn):
             else:
                 y = add(o2, x2) if add_residual else o2
         ctx.whole = whole
+        ctx.qkv_layout = qkv_layout if whole else 0      # how the saved qkv is stored (planes for bf16 heads of 64)
         ctx.save_for_backward(x2, g, mean, rstd, xn if ln_w is not None else None, qkv, o, lse, w_qkv, w_out)
         ctx.meta = (B, N, D, heads, dh, add_residual, cdt, ln_w is not None, b_out is not None,
                     ln_w.dtype if ln_w is not None else None, x.dtype)
@@ -1078,7 +1085,7 @@ class AttnBlockFn(_BlockFn):
                 do = linear_bwd_x(dy2, compute_copy(w_out, cdt), w_t=weight_t(w_out, cdt))
             else:
                 do = dy2
-            dqkv2 = attn_bwd(qkv, o, do.view(B, N, inner), lse, B, N, heads, dh).view(B * N, 3 * inner)
+            dqkv2 = attn_bwd(qkv, o, do.view(B, N, inner), lse, B, N, heads, dh, ctx.qkv_layout).view(B * N, 3 * inner)
             ps_weight(ps, dqkv2, xn_)
             s_bq = s_ln = None
             if ctx.bqkv_dtype is not None:
@@ -1112,7 +1119,7 @@ class AttnBlockFn(_BlockFn):
                                            _p(g), _p(mean), _p(rstd), _p(compute_copy(w_qkv, cdt)),
                                            _p(weight_t(w_qkv, cdt)), _p(compute_copy(w_out, cdt)),
                                            _p(weight_t(w_out, cdt)), _p(dx), _p(dg), _p(db), _p(dwq), _p(dbq), _p(dwo),
-                                           _p(dbo), _p(ws), _stream()), "vitmi_attn_block_bwd")
+                                           _p(dbo), _p(ws), ctx.qkv_layout, _stream()), "vitmi_attn_block_bwd")
             dx = dx.view(B, N, D)
             if dx.dtype != in_dtype:
                 dx = cast(dx, in_dtype)
@@ -1131,7 +1138,7 @@ class AttnBlockFn(_BlockFn):
             do = linear_bwd_x(dy2, wo, w_t=weight_t(w_out, cdt))
         else:
             do = dy2
-        dqkv = attn_bwd(qkv, o, do.view(B, N, inner), lse, B, N, heads, dh)
+        dqkv = attn_bwd(qkv, o, do.view(B, N, inner), lse, B, N, heads, dh, ctx.qkv_layout)
         dqkv2 = dqkv.view(B * N, 3 * inner)
         wq = compute_copy(w_qkv, cdt)
         dwq = linear_bwd_w(dqkv2, xn).to(w_qkv.dtype)
