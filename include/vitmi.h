@@ -414,6 +414,10 @@ int vitmi_ff_block_infer(int rows, int D, int M, const void* x, float eps, const
  *   vitmi_seg_combine           out[c] = sum_i coef[i] x[i][c]  (vector parameters: x = the per-image sums)
  *   vitmi_seg_scale_rows        out[t,:] = x[t,:] * coef[t / seg]: one operand of a weight-gradient product, so that
  *                               vitmi_gemm_wgrad(dy, coef-scaled x) = sum_i c_i dy_i^T x_i */
+/* vitmi_wgrad_sqnorm on bf16 images of up to 256 tokens uses || U^T V ||_F^2 = sum_{t,t'} (U U^T)[t,t'] (V V^T)[t,t']:
+ * two token Gram matrices per image instead of the gradient (3x fewer flops for the MLP weights at 197 tokens);
+ * vitmi_debug_set_ghost_norms(0) switches back to the tiles of the gradient itself (process-wide; for A/B timing). */
+int vitmi_debug_set_ghost_norms(int on);
 long long vitmi_wgrad_sqnorm_workspace_bytes(int dt, int P, int Q, int T, int seg);
 int vitmi_wgrad_sqnorm(int dt, int P, int Q, int T, int seg, const void* U, long long ldu, const void* V, long long ldv,
                        float* sqnorm, void* workspace, void* stream);

@@ -116,11 +116,24 @@ def test_noise_statistics_and_reproducibility():
     assert abs(noise.std().item() - 2.0) < 0.05 and abs(noise.mean().item()) < 0.05
 
 
-@pytest.mark.parametrize("P,Q,seg,nseg", [(512, 512, 70, 130), (768, 512, 197, 40), (128, 256, 33, 600), (96, 200, 17, 9)])
-def test_weight_gradient_norms_many_segments(P, Q, seg, nseg):
-    """vitmi_wgrad_sqnorm where a block walks several images (more images than one round of blocks has room for),
-    segments that are not multiples of the 64-token tile, a ragged last segment, and the unaligned fallback."""
+@pytest.mark.parametrize("gram", [1, 0], ids=["gram", "gradient_tiles"])
+@pytest.mark.parametrize("P,Q,seg,nseg", [(512, 512, 70, 130), (768, 512, 197, 40), (128, 256, 33, 600), (96, 200, 17, 9),
+                                          (3072, 768, 197, 64), (768, 2304, 256, 7), (384, 1536, 300, 5), (64, 64, 2, 50)])
+def test_weight_gradient_norms_many_segments(P, Q, seg, nseg, gram):
+    """vitmi_wgrad_sqnorm through the token Gram matrices (images of up to 256 tokens) and through the per-image tiles of
+    the gradient, where a block walks several images (more images than one round of blocks has room for): segments
+    that are not multiples of the 16- and 64-token tiles, a ragged last segment, images beyond 256 tokens, and the
+    unaligned fallback."""
     from visiontransformer_amd import ops
+    from visiontransformer_amd._lib import lib
+    lib.vitmi_debug_set_ghost_norms(gram)
+    try:
+        _norms_case(ops, P, Q, seg, nseg)
+    finally:
+        lib.vitmi_debug_set_ghost_norms(1)
+
+
+def _norms_case(ops, P, Q, seg, nseg):
     gen = torch.Generator().manual_seed(P + seg)
     T = seg * nseg - 5                                                      # the last image is 5 tokens short
     dy = torch.randn(T, P, generator=gen).to(DEV).bfloat16()

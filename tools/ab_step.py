@@ -62,6 +62,26 @@ def main():
                 step()
             torch.cuda.synchronize()
             res[name].append((time.perf_counter() - t0) / steps * 1e3)
+    if os.environ.get("AB_FAMILIES"):
+        # per-family GPU time of each configuration (launch timers on every family over two steps)
+        from visiontransformer_amd import _lib
+        for name, cfg in cfgs:
+            apply(cfg)
+            step()
+            torch.cuda.synchronize()
+            lib.vitmi_prof_select(-1)
+            lib.vitmi_prof_reset()
+            lib.vitmi_prof_enable(1)
+            step()
+            step()
+            torch.cuda.synchronize()
+            lib.vitmi_prof_enable(0)
+            fams = []
+            for fam in range(_lib.FAM_COUNT):
+                ms, work, n = _lib.prof_read(fam)
+                if n:
+                    fams.append((ms / 2, lib.vitmi_prof_name(fam).decode()))
+            print(name, " ".join(f"{nm.split('|')[-1][:28]}={ms:.3f}" for ms, nm in sorted(fams, reverse=True)[:9]), flush=True)
     for name, _ in cfgs:
         v = res[name]
         print(f"{name:24s} ms/step: " + " ".join(f"{t:7.3f}" for t in v) + f"   min {min(v):7.3f}  -> {256 / min(v) * 1e3:7.0f} img/s",

@@ -78,6 +78,7 @@ SIGNATURES = {
     "vitmi_attn_block_bwd_workspace_bytes": (L, [I, I, I, I, I, I]),
     "vitmi_attn_block_bwd": (I, [I, I, I, I, I, I] + [P] * 21 + [I, P]),
     "vitmi_transpose_cast_multi": (I, [P, P, I, L, P]),
+    "vitmi_debug_set_ghost_norms": (I, [I]),
     "vitmi_wgrad_sqnorm_workspace_bytes": (L, [I, I, I, I, I]),
     "vitmi_wgrad_sqnorm": (I, [I, I, I, I, I, P, L, P, L, P, P, P]),
     "vitmi_seg_colsum_sqnorm": (I, [P, I, L, I, L, I, P, P, P]),

@@ -1281,6 +1281,113 @@ __global__ __launch_bounds__(256) void tn_batch_reduce_kernel(const TnBatch tb) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-image squared Frobenius norm of a weight gradient without forming it ("ghost" norm):
+//     || U_i^T V_i ||_F^2 = sum over token pairs (t, t') of (U_i U_i^T)[t][t'] * (V_i V_i^T)[t][t'],
+// U_i [n, P] and V_i [n, Q] the rows of image i (n <= 256 tokens).  Two Gram matrices of n x n cost
+// 2 n^2 (P + Q) flops where the gradient itself costs 2 n P Q (3x fewer at 197 tokens for the MLP weights), and
+// nothing is written but one float.  One 16-wave workgroup per image: the image's rows stream through LDS in 64-deep
+// k-tiles (two stages, rows past n zero-filled, the swizzled row image of the nt kernels), each wave owns up to TPW
+// 16 x 16 tiles of the upper triangle (both Grams in the same registers' layout, so the final product is elementwise
+// in registers; off-diagonal tiles count twice), and the workgroup's sum is ADDED to sqnorm[i] by one thread.
+// ------------------------------------------------------------------------------------------------
+template <int TPW>
+__global__ __launch_bounds__(1024) void ghost_sqnorm_kernel(const bf16_t* __restrict__ U, long long ldu, int P,
+                                                            const bf16_t* __restrict__ V, long long ldv, int Q, int T,
+                                                            int seg, int nt, float* __restrict__ sqnorm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int r0 = blockIdx.x * seg;
+    const int n = min(seg, T - r0);
+    const int stage_elems = nt * 16 * TK;
+    const int ntiles = nt * (nt + 1) / 2;
+    // this wave's tiles: TPW consecutive entries of the row-major upper triangle (mostly one tile row: its fragment is
+    // read once per k-step)
+    int tr[TPW], tc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        int t = wave * TPW + j, r = 0;
+        if (t >= ntiles) t = -1;
+        if (t >= 0)
+            while (t >= nt - r) {
+                t -= nt - r;
+                ++r;
+            }
+        tr[j] = t < 0 ? -1 : r;
+        tc[j] = t < 0 ? -1 : r + t;
+    }
+    f32x4 acc[2][TPW];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) acc[g][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // groups of 8 rows: 2 * nt of them, group g by wave g % 16
+    auto stage = [&](const bf16_t* base, long long ld, int K, int k0, bf16_t* dst) {
+        for (int g = wave; g < 2 * nt; g += 16) {
+            const int r = g * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz_nt(r);
+            const int gk = k0 + c * 8;
+            const void* src = (r < n && gk < K) ? (const void*)(base + (long long)(r0 + r) * ld + gk) : (const void*)g_zero16;
+            glds16(src, dst + g * 8 * TK);
+        }
+    };
+    const int nkU = (P + TK - 1) / TK, nkV = (Q + TK - 1) / TK, nk = nkU + nkV;
+    auto stage_it = [&](int it, bf16_t* dst) {
+        if (it < nkU)
+            stage(U, ldu, P, it * TK, dst);
+        else
+            stage(V, ldv, Q, (it - nkU) * TK, dst);
+    };
+    stage_it(0, smem);
+    __syncthreads();
+    for (int it = 0; it < nk; ++it) {
+        const bf16_t* cur = smem + (it & 1) * stage_elems;
+        if (it + 1 < nk) stage_it(it + 1, smem + ((it + 1) & 1) * stage_elems);
+        const bool second = it >= nkU;
+#pragma unroll
+        for (int ks = 0; ks < TK / 32; ++ks) {
+            bf16x8 fa = frag_nt(cur, (tr[0] < 0 ? 0 : tr[0]) * 16 + fr, ks * 4 + fg);
+            int have = tr[0];
+#pragma unroll
+            for (int j = 0; j < TPW; ++j) {
+                if (tr[j] < 0) continue;
+                if (tr[j] != have) {
+                    fa = frag_nt(cur, tr[j] * 16 + fr, ks * 4 + fg);
+                    have = tr[j];
+                }
+                const bf16x8 fb = frag_nt(cur, tc[j] * 16 + fr, ks * 4 + fg);
+                if (second)
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[1][j], 0, 0, 0);
+                else
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[0][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+        if (tr[j] < 0) continue;
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t = fmaf(acc[0][j][r], acc[1][j][r], t);
+        tot += tr[j] == tc[j] ? t : 2.f * t;
+    }
+    tot = wave_sum(tot);
+    if (lane == 0) red[wave] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        sqnorm[blockIdx.x] += t;
+    }
+}
+
 __global__ void slab_reduce_kernel(const float* __restrict__ slabs, long long slab_stride, int nslabs,
                                    float* __restrict__ out, long long n4) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1739,6 +1846,39 @@ int vitmi_gemm_tn_seg_sq(int P, int Q, int T, int seg, const void* U, long long 
                          float* partial, int* tiles, hipStream_t s) {
     if (P >= 512 && Q >= 512) return launch_tn_seg<256, 2, 4>(P, Q, T, seg, U, ldu, V, ldv, partial, tiles, s);
     return launch_tn_seg<128, 2, 2>(P, Q, T, seg, U, ldu, V, ldv, partial, tiles, s);
+}
+
+// per-image || U_i^T V_i ||_F^2 ADDED to sqnorm[i] (images = segments of `seg` consecutive rows, seg <= 256): the Gram form
+bool vitmi_gemm_ghost_sq_ok(int P, int Q, int seg, const void* U, long long ldu, const void* V, long long ldv) {
+    return seg >= 1 && seg <= 256 && P % 8 == 0 && Q % 8 == 0 && ldu % 8 == 0 && ldv % 8 == 0 && al16(U) && al16(V);
+}
+template <int TPW>
+static int launch_ghost(int P, int Q, int T, int seg, int nt, const void* U, long long ldu, const void* V, long long ldv,
+                        float* sqnorm, hipStream_t s) {
+    static unsigned long long done = 0;
+    const size_t lds = 2 * (size_t)nt * 16 * TK * sizeof(bf16_t);
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(ghost_sqnorm_kernel<TPW>), 2 * (size_t)16 * 16 * TK * sizeof(bf16_t), &done);
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL(ghost_sqnorm_kernel<TPW>, dim3(ceil_div(T, seg)), dim3(1024), lds, s, (const bf16_t*)U, ldu, P,
+                       (const bf16_t*)V, ldv, Q, T, seg, nt, sqnorm);
+    VITMI_LAUNCH_CHECK("vitmi_wgrad_sqnorm(gram)");
+    return VITMI_OK;
+}
+int vitmi_gemm_ghost_sq(int P, int Q, int T, int seg, const void* U, long long ldu, const void* V, long long ldv,
+                        float* sqnorm, hipStream_t s) {
+    const int nt = ceil_div(seg, 16);
+    const int tpw = ceil_div(nt * (nt + 1) / 2, 16);
+    switch (tpw) {
+        case 1: return launch_ghost<1>(P, Q, T, seg, nt, U, ldu, V, ldv, sqnorm, s);
+        case 2: return launch_ghost<2>(P, Q, T, seg, nt, U, ldu, V, ldv, sqnorm, s);
+        case 3: return launch_ghost<3>(P, Q, T, seg, nt, U, ldu, V, ldv, sqnorm, s);
+        case 4: return launch_ghost<4>(P, Q, T, seg, nt, U, ldu, V, ldv, sqnorm, s);
+        case 5: return launch_ghost<5>(P, Q, T, seg, nt, U, ldu, V, ldv, sqnorm, s);
+        case 6: return launch_ghost<6>(P, Q, T, seg, nt, U, ldu, V, ldv, sqnorm, s);
+        case 7: return launch_ghost<7>(P, Q, T, seg, nt, U, ldu, V, ldv, sqnorm, s);
+        case 8: return launch_ghost<8>(P, Q, T, seg, nt, U, ldu, V, ldv, sqnorm, s);
+        default: return launch_ghost<9>(P, Q, T, seg, nt, U, ldu, V, ldv, sqnorm, s);
+    }
 }
 
 int vitmi_gemm_tn_fast(int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv, float* C,

@@ -11,6 +11,9 @@ int vitmi_gemm_tn_seg_sq(int P, int Q, int T, int seg, const void* U, long long 
                          float* partial, int* tiles, hipStream_t s);
 bool vitmi_gemm_tn_fast_ok(int P, int Q, const void* U, long long ldu, const void* V, long long ldv, const void* C,
                            long long ldc);
+bool vitmi_gemm_ghost_sq_ok(int P, int Q, int seg, const void* U, long long ldu, const void* V, long long ldv);
+int vitmi_gemm_ghost_sq(int P, int Q, int T, int seg, const void* U, long long ldu, const void* V, long long ldv,
+                        float* sqnorm, hipStream_t s);
 
 namespace {
 
@@ -247,6 +250,14 @@ bool fast_seg_ok(int dt, int P, int Q, const void* U, long long ldu, const void*
 
 }  // namespace
 
+// 1 (default): per-image weight-gradient norms of images up to 256 tokens through the token Gram matrices; 0: through
+// the per-image tiles of the gradient itself (for A/B timing and for checking one against the other)
+static int g_ghost_norms = 1;
+extern "C" int vitmi_debug_set_ghost_norms(int on) {
+    g_ghost_norms = on ? 1 : 0;
+    return VITMI_OK;
+}
+
 extern "C" long long vitmi_wgrad_sqnorm_workspace_bytes(int dt, int P, int Q, int T, int seg) {
     if (P <= 0 || Q <= 0 || T <= 0 || seg <= 0) return 0;
     const long long nseg = (T + seg - 1) / seg;
@@ -262,6 +273,13 @@ extern "C" int vitmi_wgrad_sqnorm(int dt, int P, int Q, int T, int seg, const vo
     VITMI_CHECK_ARG(P > 0 && Q > 0 && T > 0 && seg > 0 && ldu >= P && ldv >= Q, "vitmi_wgrad_sqnorm: bad shape");
     hipStream_t s = as_stream(stream);
     const int nseg = (T + seg - 1) / seg;
+    // images of up to 256 tokens: the norm from the two token Gram matrices (2 n^2 (P + Q) flops instead of 2 n P Q,
+    // no per-tile partial sums); worth it once the gradient is larger than the Grams
+    if (g_ghost_norms && dt == VITMI_BF16 && seg >= 2 && (long long)P * Q > (long long)seg * (P + Q) &&
+        vitmi_gemm_ghost_sq_ok(P, Q, seg, U, ldu, V, ldv)) {
+        ProfScope prof(VITMI_FAM_OTHER, s, 2.0 * nseg * (double)seg * seg * (P + Q));
+        return vitmi_gemm_ghost_sq(P, Q, T, seg, U, ldu, V, ldv, sqnorm, s);
+    }
     if (fast_seg_ok(dt, P, Q, U, ldu, V, ldv)) {
         int tiles = 0;
         int rc = vitmi_gemm_tn_seg_sq(P, Q, T, seg, U, ldu, V, ldv, (float*)workspace, &tiles, s);
