@@ -47,7 +47,11 @@ def ops():
 # the ragged M leaves 100 rows of the last 256-row tile empty
 @pytest.mark.parametrize("M,N,K", [(M_BENCH, 2304, 768), (M_BENCH, 768, 768), (M_BENCH, 768, 3072),
                                    (M_BENCH, 768, 2304), (M_BENCH, 3072, 768), (M_BENCH - 100, 768, 768),
-                                   (M_BENCH - 100, 3072, 768)])
+                                   (M_BENCH - 100, 3072, 768),
+                                   # the 384-wide model (timm-style ViT-S/16): N = 384 and 1152 end in a half-empty 256-wide column tile,
+                                   # K = 384 is six K-tiles, 64 a single one
+                                   (M_BENCH, 384, 384), (M_BENCH, 1152, 384), (M_BENCH, 384, 1536), (M_BENCH, 384, 1152),
+                                   (M_BENCH - 100, 384, 384), (M_BENCH - 3, 1152, 64), (M_BENCH, 384, 128)])
 def test_phased_nt_gemm_forward_epilogues_at_bench_shapes(ops, M, N, K):
     """linear_fwd -> gemm_nt_phased_kernel<NONE,bf16> (plain, bias + residual), <GELU,bf16> (bias, pre-activation
     written out) and <NONE,f32>."""
@@ -71,7 +75,7 @@ def test_phased_nt_gemm_forward_epilogues_at_bench_shapes(ops, M, N, K):
         # <GELU> evaluates the erf form, <GELU_D> the fitted sigmoid form (3.8e-5 apart before rounding): equal up to
         # a bf16 unit in the last place
         assert rel_err(h2, h) < 8e-3 and rel_err(deriv(gp), pr.grad) < 1e-2
-    if N == 768 and K == 768:
+    if (N == 768 and K == 768) or (N == 384 and K == 384):
         y32, _ = ops.linear_fwd(xd, wd, bd, out_dtype=torch.float32)
         assert rel_err(y32, pre + b) < 2e-3
 
