@@ -204,13 +204,18 @@ def test_vit_b16_block_at_batch_128_against_oracle():
     assert worst[0] < 2e-2, worst
 
 
-@pytest.mark.parametrize("dtype,tol,B", [(torch.float32, 1e-4, 8), (BF, 2e-2, 32)])
+@pytest.mark.parametrize("dtype,tol,B", [(torch.float32, 1e-4, 8), (BF, 2e-2, 32), (BF, 2e-2, 8)])
 def test_vit_b16_full_depth_against_oracle(dtype, tol, B):
     """The benchmark's model at its full depth (12 blocks of D 768, H 12, dh 64, mlp 3072, 197 tokens): what twelve
-    layers of rounding add up to, against the CPU oracle.  Logits, loss and every gradient.  bf16 at batch 32: worst
-    gradient 1.4e-2 by the maximum measure, 1.1e-2 rms; at batch 8 single elements of single tensors (the classifier
-    weight, one LayerNorm weight) reach 2.2-2.4e-2 with the rms at 1.2e-2 (tools/depth_diag.py): a gradient element
-    there is a sum over eight images only."""
+    layers of rounding add up to, against the CPU oracle.  Logits, loss and every gradient, all at the plain bar.
+
+    One documented exception, bf16 at batch 8: a gradient element there is a sum over eight images only and single
+    elements of the classifier weight's gradient reach 2.0-2.6e-2 by the maximum measure (rms 0.9e-2).  The cause is
+    the bf16 residual stream: torch under bf16 autocast, whose residual stream stays fp32, is at 0.6e-2 on that
+    tensor, while the SAME oracle run by torch on this GPU with parameters and every activation in bf16 is at 2.2e-2
+    (tools/depth_diag.py prints all three).  A tensor above the bar is therefore accepted only if that all-bf16 run
+    is above the bar on it too, the HIP path is within 1.5x of it, and the tensor's rms error is under the bar; at
+    most two tensors may take that exit."""
     from visiontransformer_amd import ViT
     kw = dict(image_size=224, patch_size=16, embed_dim=768, num_classes=100, depth=12, heads=12, mlp_dim=3072,
               dim_head=64)
@@ -228,7 +233,19 @@ def test_vit_b16_full_depth_against_oracle(dtype, tol, B):
     assert rel_err(logits, logits_ref) < tol
     assert abs(loss.item() - loss_ref.item()) < tol * max(1.0, abs(loss_ref.item()))
     errs = sorted(((rel_err(p.grad, grads_ref[k]), k) for k, p in m.named_parameters()), reverse=True)
-    assert errs[0][0] < tol, errs[:5]
+    over = [(e, k) for e, k in errs if not e < tol]
+    if over and dtype == BF and B == 8:
+        assert len(over) <= 2, errs[:5]
+        pb = {k: v.to(DEV, BF) for k, v in params.items()}
+        _, _, grads_bf = vit_oracle.loss_and_grads(pb, x.to(DEV, BF), y.to(DEV), 12)
+        grads_hip = dict((k, p.grad) for k, p in m.named_parameters())
+        for e, k in over:
+            yard = rel_err(grads_bf[k].float(), grads_ref[k])
+            ref = grads_ref[k].double()
+            rms = ((grads_hip[k].double().cpu() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+            assert yard > tol and e <= 1.5 * yard and rms < tol, (k, e, yard, rms)
+    else:
+        assert not over, errs[:5]
 
 
 @pytest.mark.parametrize("T,P0,Q0,P1,Q1", [(50432, 384, 1536, 1536, 384), (50432, 768, 3072, 3072, 768),

@@ -93,22 +93,9 @@ def test_host_class_contract_without_a_gpu():
     out, masks = JigsawPuzzleMaskedRegion(32, 4, 8, 2, mask_type="pps", device="cpu")(x0)   # the reference's final else
     assert out is x0 and masks is None
     assert random.getstate() == state[0] and np.array_equal(np.random.get_state()[1], state[1])   # no mask drawn
-    # inside the reference tree the bank comes from the caller's own dataloader.public_data (trainer.py:196-203 passes
-    # pub_data_dir only): a stand-in module shows the constructor asks it with the reference's arguments
-    import sys
-    import types
-    seen = {}
-
-    def public_data(root_dir, img_size=224, patch_size=16, length=256, random_seed=101, channels=3):
-        seen.update(root_dir=root_dir, img_size=img_size, patch_size=patch_size, channels=channels)
-        return torch.arange(5 * 48 * 64, dtype=torch.float32).view(5, 48, 64)
-
-    sys.modules["dataloader"] = types.SimpleNamespace(public_data=public_data)
-    try:
-        jp = JigsawPuzzleMaskedRegion(32, 4, 8, 2, mask_type="pbf", pub_data_dir="/data/public/", device="cpu")
-    finally:
-        del sys.modules["dataloader"]
-    assert seen == dict(root_dir="/data/public/", img_size=32, patch_size=4, channels=3)
+    # the bank is handed in by the caller ([P, C*p*p, L], the tensor dataloader.py:17-37 builds); no module is imported
+    bank = torch.arange(5 * 48 * 64, dtype=torch.float32).view(5, 48, 64)
+    jp = JigsawPuzzleMaskedRegion(32, 4, 8, 2, mask_type="pbf", pub_data_dir="/data/public/", device="cpu", pub_data=bank)
     assert tuple(jp.pub_data.shape) == (5, 48, 64) and tuple(jp._bank.shape) == (5, 3, 32, 32)
     j = JigsawPuzzleMaskedRegion(32, 4, 16, 2, mask_type="orain", device="cpu")
     random.seed(3), np.random.seed(3)

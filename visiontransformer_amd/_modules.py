@@ -20,6 +20,19 @@ def pair(t):
 
 class _HipModule(nn.Module):
     compute_dtype = torch.bfloat16
+    # True: the module computes in fp32 whatever the model's compute dtype (the classifier head: a few rows per image,
+    # so exact arithmetic there is free and keeps three bf16 roundings out of the logits and of the head's gradients)
+    pin_float32 = False
+
+
+def set_module_compute_dtype(model, dtype):
+    """torch.bfloat16 (MFMA path, default) or torch.float32 (exact-fp32 kernels) on every HIP module of `model`."""
+    if dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("compute dtype must be torch.bfloat16 or torch.float32")
+    for m in model.modules():
+        if isinstance(m, _HipModule):
+            m.compute_dtype = torch.float32 if m.pin_float32 else dtype
+    return model
 
 
 class LayerNorm(nn.LayerNorm, _HipModule):
@@ -261,6 +274,9 @@ class _VITBase(_HipModule):
             Linear(embed_dim, num_classes),
         )
         self.mlp_head[1].out_dtype = torch.float32
+        for m in self.mlp_head:                 # [B, D] rows: LayerNorm and the classifier run in fp32
+            m.pin_float32 = True
+            m.compute_dtype = torch.float32
         self.embed_dim = embed_dim
         self.num_tokens = num_patches + 1
 
@@ -273,12 +289,7 @@ class _VITBase(_HipModule):
     # ---- runtime switches ---------------------------------------------------------------
     def set_compute_dtype(self, dtype):
         """torch.bfloat16 (MFMA path, default) or torch.float32 (exact-fp32 kernels)."""
-        if dtype not in (torch.bfloat16, torch.float32):
-            raise TypeError("compute dtype must be torch.bfloat16 or torch.float32")
-        for m in self.modules():
-            if isinstance(m, _HipModule):
-                m.compute_dtype = dtype
-        return self
+        return set_module_compute_dtype(self, dtype)
 
     @staticmethod
     def set_gelu(mode):

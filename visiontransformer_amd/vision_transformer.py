@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._modules import (LayerNorm, Linear, PatchEmbed as _PatchEmbedBase, ProbsTap, _CastFn, _HipModule,
+from ._modules import (LayerNorm, Linear, PatchEmbed as _PatchEmbedBase, ProbsTap, _CastFn, _HipModule, set_module_compute_dtype,
                        _has_backward_hooks, attention_with_probability_gradients)
 
 __all__ = ["Attention", "Mlp", "Block", "PatchEmbed", "VisionTransformer", "vit_small_patch16_224",
@@ -201,8 +201,7 @@ class VisionTransformer(_HipModule):
         self.fc_norm = norm_layer(embed_dim) if use_fc_norm else nn.Identity()
         self.head_drop = nn.Dropout(drop_rate)
         self.head = Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
-        if isinstance(self.head, Linear):
-            self.head.out_dtype = torch.float32
+        self._pin_head()
         if weight_init != 'skip':
             self.init_weights(weight_init)
 
@@ -220,14 +219,18 @@ class VisionTransformer(_HipModule):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
+    def _pin_head(self):
+        # the modules that only ever see the pooled [B, D] rows compute in fp32 and the logits leave in fp32
+        for m in (self.fc_norm, self.head):
+            if isinstance(m, _HipModule):
+                m.pin_float32 = True
+                m.compute_dtype = torch.float32
+        if isinstance(self.head, Linear):
+            self.head.out_dtype = torch.float32
+
     def set_compute_dtype(self, dtype):
         """torch.bfloat16 (MFMA path, default) or torch.float32 (exact-fp32 kernels)."""
-        if dtype not in (torch.bfloat16, torch.float32):
-            raise TypeError("compute dtype must be torch.bfloat16 or torch.float32")
-        for m in self.modules():
-            if isinstance(m, _HipModule):
-                m.compute_dtype = dtype
-        return self
+        return set_module_compute_dtype(self, dtype)
 
     def no_weight_decay(self):
         return {'pos_embed', 'cls_token', 'dist_token'}
@@ -241,9 +244,7 @@ class VisionTransformer(_HipModule):
             assert global_pool in ('', 'avg', 'token')
             self.global_pool = global_pool
         self.head = Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
-        if isinstance(self.head, Linear):
-            self.head.out_dtype = torch.float32
-            self.head.compute_dtype = self.compute_dtype
+        self._pin_head()
 
     def _seq_ord(self, n, unk_mask, device):
         # tim/models/vision_transformer.py:556-564: masked positions read the last table row
@@ -275,6 +276,15 @@ class VisionTransformer(_HipModule):
         return x if pre_logits else self.head(x)
 
     def forward(self, x, unk_mask=None):
+        if self.global_pool == 'token' and isinstance(self.norm, LayerNorm):
+            # LayerNorm works row by row and only the class row is read: normalise that row alone, in fp32
+            # (tim/models/vision_transformer.py:618-633 normalises all rows and then drops all but one)
+            x = self.blocks(self._pos_embed(self.patch_embed(x), unk_mask))[:, 0]
+            if x.dtype != torch.float32:
+                x = _CastFn.apply(x, torch.float32) if x.requires_grad else ops.cast(x, torch.float32)
+            x = ops.LayerNormFn.apply(x.contiguous(), self.norm.weight, self.norm.bias, self.norm.eps)
+            x = self.head_drop(self.fc_norm(x))
+            return self.head(x)
         return self.forward_head(self.forward_features(x, unk_mask))
 
 
