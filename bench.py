@@ -257,6 +257,11 @@ def main():
 
     from visiontransformer_amd import ViT, ViT_mask, _lib, ops
     from visiontransformer_amd.optim import FusedAdam
+    # A/B switches of the library (same box, one run each): VITMI_WGRAD_OVERLAP = -1 / 0 / 1, VITMI_SMALL_FUSED = mask
+    for env, setter in (("VITMI_WGRAD_OVERLAP", _lib.lib.vitmi_debug_set_wgrad_overlap),
+                        ("VITMI_SMALL_FUSED", _lib.lib.vitmi_debug_set_small_fused)):
+        if os.environ.get(env, "") != "":
+            _lib.check(setter(int(os.environ[env])))
     from visiontransformer_amd.parallel import GradReducer, broadcast_parameters
 
     kw, kind, batch, gflop_img = WORKLOADS[args.workload]

@@ -1,0 +1,108 @@
+"""The one-launch sub-block kernels of the small geometry (embedding width <= 256) against the launch-per-step form of
+the same C-ABI block calls, and against an fp64 evaluation of the sub-block (mymodel/ViT.py:52-73, 119-120)."""
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+DEV = "cuda:0"
+
+
+def _ff_block(rows, D, M, fused, erf, seed=0):
+    from visiontransformer_amd._lib import check, lib
+    from visiontransformer_amd.ops import _p, _stream
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, D, generator=g).to(DEV, BF)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(D, generator=g)).to(DEV)
+    w1 = (torch.randn(M, D, generator=g) * D ** -0.5).to(DEV, BF)
+    b1 = (0.1 * torch.randn(M, generator=g)).to(DEV)
+    w2 = (torch.randn(D, M, generator=g) * M ** -0.5).to(DEV, BF)
+    b2 = (0.1 * torch.randn(D, generator=g)).to(DEV)
+    out = dict(xn=torch.empty(rows, D, dtype=BF, device=DEV), mean=torch.empty(rows, device=DEV),
+               rstd=torch.empty(rows, device=DEV), u=torch.empty(rows, M, dtype=BF, device=DEV),
+               h=torch.empty(rows, M, dtype=BF, device=DEV), y=torch.empty(rows, D, dtype=BF, device=DEV))
+    check(lib.vitmi_debug_set_small_fused(-1 if fused else 0))
+    check(lib.vitmi_set_gelu_mode(1 if erf else 0))
+    try:
+        check(lib.vitmi_ff_block_fwd(1, rows, D, M, _p(x), _p(gamma), _p(beta), 1e-5, _p(w1), _p(b1), _p(w2), _p(b2),
+                                     _p(out["xn"]), _p(out["mean"]), _p(out["rstd"]), _p(out["u"]), _p(out["h"]),
+                                     _p(out["y"]), _stream()), "vitmi_ff_block_fwd")
+        torch.cuda.synchronize()
+    finally:
+        check(lib.vitmi_debug_set_small_fused(-1))
+        check(lib.vitmi_set_gelu_mode(0))
+    ins = dict(x=x, gamma=gamma, beta=beta, w1=w1, b1=b1, w2=w2, b2=b2)
+    return ins, out
+
+
+@pytest.mark.parametrize("erf", [False, True])
+@pytest.mark.parametrize("rows,D,M", [(256 * 65, 192, 512), (64 * 65, 192, 512), (37, 64, 128), (1000, 256, 1024),
+                                      (16 * 5 * 3 + 1, 128, 96), (96, 96, 32)])
+def test_ff_block_forward_one_launch_against_steps_and_fp64(rows, D, M, erf):
+    ins, fused = _ff_block(rows, D, M, True, erf)
+    _, steps = _ff_block(rows, D, M, False, erf)
+    # the two forms: same arithmetic per element up to the summation order inside the matrix instructions
+    for k in ("mean", "rstd"):
+        assert rel_err(fused[k], steps[k]) < 1e-6, k
+    for k in ("xn", "h", "y"):
+        assert rel_err(fused[k].float(), steps[k].float()) < 8e-3, k     # one bf16 unit of the largest element
+    uf = (fused["u"].view(torch.float16) if not erf else fused["u"]).float()
+    us = (steps["u"].view(torch.float16) if not erf else steps["u"]).float()
+    assert rel_err(uf, us) < 8e-3
+    # fp64 evaluation from the same bf16 operands
+    x = ins["x"].double()
+    xn = torch.nn.functional.layer_norm(x, (D,), ins["gamma"].double(), ins["beta"].double(), 1e-5)
+    pre = xn.to(BF).double() @ ins["w1"].double().t() + ins["b1"].double()
+    h = torch.nn.functional.gelu(pre)
+    y = h.to(BF).double() @ ins["w2"].double().t() + ins["b2"].double() + x
+    assert rel_err(fused["xn"].double(), xn) < 2e-2
+    assert rel_err(fused["h"].double(), h) < 2e-2
+    assert rel_err(fused["y"].double(), y) < 2e-2
+    if erf:
+        assert rel_err(uf.double(), pre) < 2e-2
+    else:
+        cdf = 0.5 * (1 + torch.erf(pre / 2 ** 0.5))
+        assert rel_err(uf.double(), cdf + pre * torch.exp(-0.5 * pre * pre) / (2 * torch.pi) ** 0.5) < 2e-2
+
+
+def _cifar_step(overlap, fused, seed=3):
+    import visiontransformer_amd as vta
+    from visiontransformer_amd import ViT
+    from visiontransformer_amd._lib import check, lib
+    torch.manual_seed(seed)
+    m = ViT.VIT(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=3, heads=12, mlp_dim=512).to(DEV).train()
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(16, 3, 32, 32, generator=g).to(DEV)
+    y = torch.randint(0, 10, (16,), generator=g).to(DEV)
+    check(lib.vitmi_debug_set_wgrad_overlap(overlap))
+    check(lib.vitmi_debug_set_small_fused(-1 if fused else 0))
+    try:
+        logits = m(x)
+        torch.nn.functional.cross_entropy(logits, y).backward()
+        torch.cuda.synchronize()
+    finally:
+        check(lib.vitmi_debug_set_wgrad_overlap(-1))
+        check(lib.vitmi_debug_set_small_fused(-1))
+    return logits.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+
+def test_weight_gradients_on_the_second_stream_change_nothing():
+    """The same kernels in the same order per stream: logits and every gradient bit-identical with the weight-gradient
+    pair on the library's second stream (forced on), on the caller's stream (off) and in the automatic mode."""
+    ref_logits, ref = _cifar_step(0, True)
+    for mode in (1, -1):
+        logits, grads = _cifar_step(mode, True)
+        assert torch.equal(logits, ref_logits)
+        for k in ref:
+            assert torch.equal(grads[k], ref[k]), (mode, k)
+
+
+def test_model_step_with_and_without_the_one_launch_kernels():
+    ref_logits, ref = _cifar_step(-1, False)
+    logits, grads = _cifar_step(-1, True)
+    assert rel_err(logits, ref_logits) < 2e-2
+    for k in ref:
+        assert rel_err(grads[k], ref[k]) < 2e-2, k

@@ -75,6 +75,8 @@ SIGNATURES = {
     "vitmi_attn_block_fwd": (I, [I, I, I, I, I, I, P, P, P, F] + [P] * 12 + [I, P]),
     "vitmi_attn_block_qkv_layout": (I, [I, I, I, I, I, I]),
     "vitmi_debug_set_qkv_planes": (I, [I]),
+    "vitmi_debug_set_small_fused": (I, [I]),
+    "vitmi_debug_set_wgrad_overlap": (I, [I]),
     "vitmi_attn_block_bwd_workspace_bytes": (L, [I, I, I, I, I, I]),
     "vitmi_attn_block_bwd": (I, [I, I, I, I, I, I] + [P] * 21 + [I, P]),
     "vitmi_transpose_cast_multi": (I, [P, P, I, L, P]),

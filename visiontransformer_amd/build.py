@@ -20,7 +20,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libvitmi_hip.so")
 ARCH = "gfx950"
-SOURCES = ["runtime.hip", "elementwise.hip", "gemm.hip", "gemm_fast.hip", "attention.hip", "rollout.hip", "blocks.hip", "persample.hip"]
+SOURCES = ["runtime.hip", "elementwise.hip", "gemm.hip", "gemm_fast.hip", "attention.hip", "rollout.hip", "blocks.hip", "persample.hip", "small.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "vitmi.h")]
 FLAGS = ["-O3", "-fPIC", "-std=c++17", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function"]
 

@@ -31,9 +31,76 @@ int input_grad(int dt, int T, int K, int N, const void* dy, const void* w, const
                       stream);
 }
 
+// ---- weight gradients beside the input-gradient chain ---------------------------------------------------------------
+// At small shapes no launch of a sub-block's backward fills the chip, and the two weight-gradient products are off
+// the critical path (nothing downstream of the call reads dW before the optimizer): they are enqueued on a second
+// stream of the library's own, each forked from the caller's stream by an event as soon as its operands exist -- the
+// first at the start of the call (dY^T H, dY^T O read the call's inputs only), the second behind the launch that
+// produces its dY operand -- and joined back before the call returns, so that they run beside the input-gradient
+// chain and the LayerNorm backward.  The caller's stream sees
+// one call as before (also under stream capture: the fork and join become graph edges).
+struct Side {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, fork2 = nullptr, join = nullptr;
+    bool failed = false;
+};
+constexpr int MAX_DEVICES = 16;
+thread_local Side tl_side[MAX_DEVICES];
+int g_overlap = -1;  // -1 automatic, 0 never, 1 always
+
+Side* side_stream() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    Side& sd = tl_side[dev];
+    if (sd.failed) return nullptr;
+    if (!sd.s) {
+        if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.fork2, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            sd.failed = true;  // e.g. first use inside a stream capture: stay on the caller's stream
+            sd.s = nullptr;
+            return nullptr;
+        }
+    }
+    return &sd;
+}
+
+// rows * width up to 8 M elements: every product of the sub-block is then a sub-wave-per-CU launch of ~10 us
+Side* overlap_side(long long rows, int D) {
+    if (g_overlap == 0) return nullptr;
+    if (g_overlap < 0 && rows * (long long)D > (8ll << 20)) return nullptr;
+    return side_stream();
+}
+
+// the second stream waits for everything enqueued on the caller's stream so far
+int side_fork(Side* sd, void* stream, bool second = false) {
+    hipEvent_t ev = second ? sd->fork2 : sd->fork;
+    hipError_t e = hipEventRecord(ev, as_stream(stream));
+    if (e == hipSuccess) e = hipStreamWaitEvent(sd->s, ev, 0);
+    return e == hipSuccess ? VITMI_OK : vitmi_hip_fail(e, "side stream fork");
+}
+int side_join(Side* sd, void* stream) {
+    hipError_t e = hipEventRecord(sd->join, sd->s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(as_stream(stream), sd->join, 0);
+    return e == hipSuccess ? VITMI_OK : vitmi_hip_fail(e, "side stream join");
+}
+
 }  // namespace
 
+extern "C" int vitmi_debug_set_wgrad_overlap(int mode) {
+    g_overlap = mode < 0 ? -1 : (mode ? 1 : 0);
+    return VITMI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ MLP block
+// the sub-block as ONE launch at the small geometry (small.hip); NOT_TAKEN = operands not 16-byte aligned, nothing enqueued
+enum { VITMI_SMALL_NOT_TAKEN = 1000 };
+bool vitmi_ff_small_ok(int dt, long long rows, int D, int M);
+int vitmi_ff_small_fwd(long long rows, int D, int M, const void* x, const float* gamma, const float* beta, float eps,
+                       const void* w1, const float* b1, const void* w2, const float* b2, void* xn, float* mean, float* rstd,
+                       void* u, void* h, void* y, int erf_pair, void* stream);
 // which epilogue pair the MLP block runs: 0 = GELU_D / MULAUX (u holds gelu'(pre-activation)), 1 = GELU / DGELU (u
 // holds the pre-activation and the backward epilogue evaluates the derivative)
 static int g_classic_gelu_pair = 0;
@@ -49,6 +116,11 @@ extern "C" int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x,
     VITMI_CHECK_ARG(x && gamma && beta && w1 && b1 && w2 && b2 && xn && mean && rstd && u && h && y,
                     "vitmi_ff_block_fwd: null pointer");
     VITMI_CHECK_ARG(rows > 0 && D > 0 && M > 0, "vitmi_ff_block_fwd: bad shape rows=%d D=%d M=%d", rows, D, M);
+    if (vitmi_ff_small_ok(dt, rows, D, M)) {
+        const int rc = vitmi_ff_small_fwd(rows, D, M, x, gamma, beta, eps, w1, b1, w2, b2, xn, mean, rstd, u, h, y,
+                                          g_classic_gelu_pair, stream);
+        if (rc != VITMI_SMALL_NOT_TAKEN) return rc;
+    }
     STEP(vitmi_layernorm_fwd(x, D, gamma, beta, xn, mean, rstd, dt, rows, D, eps, stream));
     STEP(vitmi_gemm(dt, rows, M, D, xn, D, 1, w1, D, 1, h, M, dt, g_classic_gelu_pair ? VITMI_EPI_GELU : VITMI_EPI_GELU_D, b1, nullptr, 0, u,
                     M, stream));
@@ -56,12 +128,16 @@ extern "C" int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x,
     return VITMI_OK;
 }
 
+// scratch of the launches on the caller's stream; the weight-gradient pair has its own region behind it (it may run
+// beside them)
+static long long ff_chain_scratch(long long rows, int D, int M) {
+    return align256(max2(vitmi_gemm_colsum_workspace_bytes(rows, M), vitmi_layernorm_bwd_workspace_bytes(rows, D)));
+}
+
 extern "C" long long vitmi_ff_block_bwd_workspace_bytes(int dt, int rows, int D, int M) {
     if (rows <= 0 || D <= 0 || M <= 0) return 0;
-    long long scratch = vitmi_gemm_wgrad_pair_workspace_bytes(dt, rows, D, M, M, D);
-    scratch = max2(scratch, vitmi_gemm_colsum_workspace_bytes(rows, M));
-    scratch = max2(scratch, vitmi_layernorm_bwd_workspace_bytes(rows, D));
-    return align256((long long)rows * M * esize(dt)) + align256((long long)rows * D * esize(dt)) + align256(scratch);
+    return align256((long long)rows * M * esize(dt)) + align256((long long)rows * D * esize(dt)) +
+           ff_chain_scratch(rows, D, M) + align256(vitmi_gemm_wgrad_pair_workspace_bytes(dt, rows, D, M, M, D));
 }
 
 extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const void* x, const void* xn,
@@ -77,12 +153,24 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
     void* du = ws;
     void* dxn = ws + align256((long long)rows * M * esize(dt));
     void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
+    void* wg_scratch = (char*)scratch + ff_chain_scratch(rows, D, M);
+    Side* sd = overlap_side(rows, D);
+    if (sd) {
+        STEP(side_fork(sd, stream));
+        STEP(vitmi_gemm_wgrad(dt, D, M, rows, dy, D, h, M, dw2, M, wg_scratch, sd->s));
+    }
     STEP(input_grad(dt, rows, M, D, dy, w2, w2_t, du, g_classic_gelu_pair ? VITMI_EPI_DGELU : VITMI_EPI_MULAUX,
                     const_cast<void*>(u), db1, scratch, stream));
-    // both weight gradients of the sub-block share the token axis: one launch where the shapes allow it
-    STEP(vitmi_gemm_wgrad_pair(dt, rows, D, M, dy, D, h, M, dw2, M, D, du, M, xn, D, dw1, scratch, stream));
+    if (sd) {
+        STEP(side_fork(sd, stream, true));
+        STEP(vitmi_gemm_wgrad(dt, M, D, rows, du, M, xn, D, dw1, D, wg_scratch, sd->s));
+    } else {
+        // both weight gradients of the sub-block share the token axis: one launch where the shapes allow it
+        STEP(vitmi_gemm_wgrad_pair(dt, rows, D, M, dy, D, h, M, dw2, M, D, du, M, xn, D, dw1, wg_scratch, stream));
+    }
     STEP(input_grad(dt, rows, D, M, du, w1, w1_t, dxn, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
     STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db2, scratch, dt, rows, D, stream));
+    if (sd) STEP(side_join(sd, stream));
     return VITMI_OK;
 }
 
@@ -134,15 +222,20 @@ extern "C" int vitmi_attn_block_fwd(int dt, int B, int N, int D, int H, int DH, 
     return VITMI_OK;
 }
 
+static long long attn_chain_scratch(int dt, int B, int N, int D, int H, int DH) {
+    const long long rows = (long long)B * N;
+    long long scratch = vitmi_attn_bwd_workspace_bytes(dt, B, N, H, DH);
+    scratch = max2(scratch, vitmi_colsum_workspace_bytes(rows, 3 * H * DH));
+    scratch = max2(scratch, vitmi_layernorm_bwd_workspace_bytes(rows, D));
+    return align256(scratch);
+}
+
 extern "C" long long vitmi_attn_block_bwd_workspace_bytes(int dt, int B, int N, int D, int H, int DH) {
     if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || DH <= 0) return 0;
     const int rows = B * N, I = H * DH;
-    long long scratch = vitmi_gemm_wgrad_pair_workspace_bytes(dt, rows, D, I, 3 * I, D);
-    scratch = max2(scratch, vitmi_attn_bwd_workspace_bytes(dt, B, N, H, DH));
-    scratch = max2(scratch, vitmi_colsum_workspace_bytes(rows, 3 * I));
-    scratch = max2(scratch, vitmi_layernorm_bwd_workspace_bytes(rows, D));
     return align256((long long)rows * I * esize(dt)) + align256((long long)rows * 3 * I * esize(dt)) +
-           align256((long long)rows * D * esize(dt)) + align256(scratch);
+           align256((long long)rows * D * esize(dt)) + attn_chain_scratch(dt, B, N, D, H, DH) +
+           align256(vitmi_gemm_wgrad_pair_workspace_bytes(dt, rows, D, I, 3 * I, D));
 }
 
 extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, const void* dy, const void* x,
@@ -162,22 +255,34 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
     void* dqkv = ws + align256((long long)rows * I * esize(dt));
     void* dxn = (char*)dqkv + align256((long long)rows * 3 * I * esize(dt));
     void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
+    void* wg_scratch = (char*)scratch + attn_chain_scratch(dt, B, N, D, H, DH);
     // dqkv lives in the workspace, so its layout is this call's own choice: planes when the three consumers below can
     // read them (a qkv bias wants the column sums of the row-major matrix; the input gradient wants the transposed weight)
     const bool dq_planes = (g_qkv_planes & 2) && !db_qkv && w_qkv_t && vitmi_qkv_planes_ok(dt, B, N, D, H, DH, xn, w_qkv_t, dqkv);
+    Side* sd = dq_planes ? nullptr : overlap_side(rows, D);  // (planes: heads of 64, never a small shape)
+    if (sd) {
+        STEP(side_fork(sd, stream));
+        STEP(vitmi_gemm_wgrad(dt, D, I, rows, dy, D, o, I, dw_out, I, wg_scratch, sd->s));
+    }
     STEP(input_grad(dt, rows, I, D, dy, w_out, w_out_t, dout, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
     STEP(vitmi_attn_bwd(qkv, o, dout, lse, nullptr, dqkv, scratch, dt, B, N, H, DH,
                         qkv_layout | (dq_planes ? VITMI_DQKV_HEAD_MAJOR : 0), stream));
     if (dq_planes) {
-        STEP(vitmi_gemm_wgrad_pair_planes(rows, D, I, dy, D, o, I, dw_out, 3 * I, D, dqkv, xn, D, dw_qkv, scratch, stream));
+        STEP(vitmi_gemm_wgrad_pair_planes(rows, D, I, dy, D, o, I, dw_out, 3 * I, D, dqkv, xn, D, dw_qkv, wg_scratch, stream));
         STEP(vitmi_gemm_from_planes(rows, D, 3 * I, dqkv, w_qkv_t, dxn, stream));
-        STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db_out, scratch, dt, rows, D, stream));
-        return VITMI_OK;
+    } else {
+        if (sd) {
+            STEP(side_fork(sd, stream, true));
+            STEP(vitmi_gemm_wgrad(dt, 3 * I, D, rows, dqkv, 3 * I, xn, D, dw_qkv, D, wg_scratch, sd->s));
+        } else {
+            STEP(vitmi_gemm_wgrad_pair(dt, rows, D, I, dy, D, o, I, dw_out, 3 * I, D, dqkv, 3 * I, xn, D, dw_qkv, wg_scratch,
+                                       stream));
+        }
+        if (db_qkv) STEP(vitmi_colsum(dqkv, dt, rows, 3 * I, 3 * I, db_qkv, scratch, stream));
+        STEP(input_grad(dt, rows, D, 3 * I, dqkv, w_qkv, w_qkv_t, dxn, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
     }
-    STEP(vitmi_gemm_wgrad_pair(dt, rows, D, I, dy, D, o, I, dw_out, 3 * I, D, dqkv, 3 * I, xn, D, dw_qkv, scratch, stream));
-    if (db_qkv) STEP(vitmi_colsum(dqkv, dt, rows, 3 * I, 3 * I, db_qkv, scratch, stream));
-    STEP(input_grad(dt, rows, D, 3 * I, dqkv, w_qkv, w_qkv_t, dxn, VITMI_EPI_NONE, nullptr, nullptr, nullptr, stream));
     STEP(vitmi_layernorm_bwd(dxn, x, D, gamma, mean, rstd, dy, dx, dgamma, dbeta, db_out, scratch, dt, rows, D, stream));
+    if (sd) STEP(side_join(sd, stream));
     return VITMI_OK;
 }
 
