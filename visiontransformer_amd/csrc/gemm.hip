@@ -8,7 +8,8 @@
 //       always [row][k] with a 16-byte row pad (144-B rows: conflict-free ds_read_b128), whatever
 //       the operand's memory layout (an operand that is contiguous along its row index is
 //       transposed on its way into LDS).
-// fp32: 64x64x16 VALU tile kernel with the same epilogue (exact fp32 FMA; parity path).
+// fp32: 64x64x16 tiles on v_mfma_f32_16x16x4_f32 (IEEE fp32 products and sums: the exact parity path) with the same
+//       epilogue; products with few output tiles (weight gradients) split K over blockIdx.z into slabs summed in order.
 //
 // The patch-embedding GEMMs reuse the bf16/fp32 cores with a loader that gathers patch
 // elements straight from the NCHW image (no im2col buffer).
@@ -290,55 +291,124 @@ struct F32Operand {
     }
 };
 
+// 64 x 64 output tile per 4-wave block, each wave a 32 x 32 quarter as 2 x 2 v_mfma_f32_16x16x4_f32 tiles (IEEE fp32
+// products and sums: the exact-arithmetic mode keeps its 1e-4 bar).  Operand fragments of that instruction: lane l
+// supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] of a 16 x 4 / 4 x 16 step and receives D[4 (l >> 4) + i][l & 15].
+// Both tiles sit in LDS as [row][k] with rows 17 floats apart.
+// blockIdx.z walks K in chunks of k_chunk (weight gradients: K = tokens, few output tiles): slab z of the partial
+// products goes to C + z * slab_stride and f32_slab_sum_kernel adds the slabs in index order.
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand B, Epilogue epi, int M, int N, int K) {
-    constexpr int TM = 64, TN = 64, TK = 16;
-    __shared__ float As[TK][TM + 4];
-    __shared__ float Bs[TK][TN + 4];
+__global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand B, Epilogue epi, int M, int N, int K,
+                                                       int k_chunk, long long slab_stride) {
+    constexpr int TM = 64, TN = 64, TK = 16, LD = TK + 1;
+    __shared__ float As[TM][LD];
+    __shared__ float Bs[TN][LD];
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int kz0 = blockIdx.z * k_chunk, kz1 = min(K, kz0 + k_chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int fr = lane & 15, fk = lane >> 4;
     const bool a_kc = A.patch ? (A.token_rows != 0) : (A.s_k == 1);
     const bool b_kc = B.patch ? (B.token_rows != 0) : (B.s_k == 1);
-    float acc[4][4];
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += TK) {
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kz0; k0 < kz1; k0 += TK) {
+        float av[4], bv[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = threadIdx.x + i * 256;
             int r, k;
             if (a_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
-            As[k][r] = A.at(m0 + r, k0 + k, K);
+            av[i] = A.at(m0 + r, k0 + k, kz1);
             if (b_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
-            Bs[k][r] = B.at(n0 + r, k0 + k, K);
+            bv[i] = B.at(n0 + r, k0 + k, kz1);
+        }
+        __syncthreads();  // the previous tile's fragments have been read
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = threadIdx.x + i * 256;
+            int r, k;
+            if (a_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
+            As[r][k] = av[i];
+            if (b_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
+            Bs[r][k] = bv[i];
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < TK; ++k) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = As[k][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = Bs[k][tx * 4 + j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + ty * 4 + i;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + tx * 4 + j;
-            if (n < N) epilogue_store<EPI, float, float>(epi, m, n, acc[i][j]);
+        for (int kk = 0; kk < TK; kk += 4) {
+            const float a0 = As[wm + fr][kk + fk], a1 = As[wm + 16 + fr][kk + fk];
+            const float b0 = Bs[wn + fr][kk + fk], b1 = Bs[wn + 16 + fr][kk + fk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
+    if (slab_stride > 0) epi.C = reinterpret_cast<float*>(epi.C) + (long long)blockIdx.z * slab_stride;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm + i * 16 + 4 * fk + r;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn + j * 16 + fr;
+                if (n < N) epilogue_store<EPI, float, float>(epi, m, n, acc[i][j][r]);
+            }
+        }
+}
+
+// out[m * ldc + n] = sum_z slabs[z][m][n] (dense M x N slabs), in slab order
+__global__ void f32_slab_sum_kernel(const float* __restrict__ slabs, int nslabs, int M, int N, float* __restrict__ out,
+                                    long long ldc) {
+    const long long total = (long long)M * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float s = slabs[i];
+        for (int z = 1; z < nslabs; ++z) s += slabs[(long long)z * total + i];
+        out[(i / N) * ldc + (i % N)] = s;
+    }
+}
+
+// K chunks for an fp32 product whose output has few tiles (weight gradients): enough blocks for two per CU, chunks of
+// at least 256.  A function of the shape alone, so that the workspace query and the launch agree.
+inline int f32_k_splits(int M, int N, int K) {
+    const long long tiles = (long long)ceil_div(M, 64) * ceil_div(N, 64);
+    if (tiles >= 256 || K < 1024) return 1;
+    long long want = (512 + tiles - 1) / tiles;
+    const long long most = K / 256;
+    if (want > most) want = most;
+    return want < 1 ? 1 : (int)want;
+}
+
+// the plain fp32 product C = A B^T, split along K through `slabs` when that pays (slabs may be null: one pass)
+inline int launch_f32_plain(const F32Operand& a, const F32Operand& b, Epilogue epi, int M, int N, int K, float* slabs,
+                            hipStream_t s, const char* what) {
+    int splits = slabs ? f32_k_splits(M, N, K) : 1;
+    int chunk = K;
+    if (splits > 1) {
+        chunk = ((K + splits - 1) / splits + 15) / 16 * 16;
+        splits = (K + chunk - 1) / chunk;
+    }
+    dim3 grid(ceil_div(N, 64), ceil_div(M, 64), splits);
+    if (splits <= 1) {
+        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
+        VITMI_LAUNCH_CHECK(what);
+        return VITMI_OK;
+    }
+    float* out = reinterpret_cast<float*>(epi.C);
+    const long long ldc = epi.ldc;
+    epi.C = slabs;
+    epi.ldc = N;
+    hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, chunk, (long long)M * N);
+    VITMI_LAUNCH_CHECK(what);
+    const int blocks = (int)std::min<long long>(((long long)M * N + 255) / 256, 1024);
+    hipLaunchKernelGGL(f32_slab_sum_kernel, dim3(blocks), dim3(256), 0, s, slabs, splits, M, N, out, ldc);
+    VITMI_LAUNCH_CHECK(what);
+    return VITMI_OK;
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -409,15 +479,15 @@ static int gemm_impl(int dt, int M, int N, int K, const void* A, long long sam, 
         F32Operand b{(const float*)B, sbn, sbk, N, 0, 0, 0, 0, 0, 0, 0, 0};
         dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
         if (epilogue == VITMI_EPI_NONE)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
         else if (epilogue == VITMI_EPI_GELU)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
         else if (epilogue == VITMI_EPI_GELU_D)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU_D>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU_D>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
         else if (epilogue == VITMI_EPI_MULAUX)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_MULAUX>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_MULAUX>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
         else
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_DGELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_DGELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
         VITMI_LAUNCH_CHECK("vitmi_gemm(f32)");
         return VITMI_OK;
     }
@@ -513,7 +583,7 @@ extern "C" int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, con
         F32Operand a{(const float*)x, 0, 0, M, 1, 1, C, H, W, p, gw, gh};
         F32Operand b{(const float*)w, K, 1, N, 0, 0, 0, 0, 0, 0, 0, 0};
         dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
-        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K);
+        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
         VITMI_LAUNCH_CHECK("vitmi_patch_embed_fwd(f32)");
         return VITMI_OK;
     }
@@ -534,8 +604,13 @@ extern "C" int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, con
 }
 
 extern "C" long long vitmi_patch_embed_bwd_w_workspace_bytes(int dt, int B, int C, int H, int W, int p, int D) {
-    if (dt != VITMI_BF16 || p <= 0) return 0;
+    if (p <= 0) return 0;
     const int E = C * p * p, T = B * (H / p) * (W / p);
+    if (dt == VITMI_F32) {
+        const int z = f32_k_splits(D, E, T);
+        return z > 1 ? (long long)(z + 1) * D * E * (long long)sizeof(float) : 0;
+    }
+    if (dt != VITMI_BF16) return 0;
     const int ns = vitmi_gemm_tn_slabs_bound(D, E, T);    // independent of the CU reservation in force
     return ns > 1 ? (long long)ns * D * E * (long long)sizeof(float) : 0;
 }
@@ -563,10 +638,7 @@ extern "C" int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, 
         VITMI_CHECK_ARG(x_dt == VITMI_F32, "vitmi_patch_embed_bwd_w: fp32 compute needs an fp32 image");
         F32Operand a{(const float*)dy, 1, D, D, 0, 0, 0, 0, 0, 0, 0, 0};
         F32Operand b{(const float*)x, 0, 0, E, 1, 0, C, H, W, p, gw, gh};
-        dim3 grid(ceil_div(E, 64), ceil_div(D, 64));
-        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, D, E, T);
-        VITMI_LAUNCH_CHECK("vitmi_patch_embed_bwd_w(f32)");
-        return VITMI_OK;
+        return launch_f32_plain(a, b, epi, D, E, T, (float*)workspace, s, "vitmi_patch_embed_bwd_w(f32)");
     }
     VITMI_CHECK_ARG(dt == VITMI_BF16, "vitmi_patch_embed_bwd_w: bad dtype %d", dt);
     StridedLoader<false> la{(const bf16_t*)dy, 1, D, D, T, al16(dy) && D % 8 == 0};
@@ -585,6 +657,10 @@ extern "C" int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, 
 }
 
 extern "C" long long vitmi_gemm_wgrad_workspace_bytes(int dt, int P, int Q, int T) {
+    if (dt == VITMI_F32) {
+        const int z = f32_k_splits(P, Q, T);  // (+1: the chunk rounding may add a slab)
+        return z > 1 ? (long long)(z + 1) * P * Q * (long long)sizeof(float) : 0;
+    }
     if (dt != VITMI_BF16) return 0;
     // sized for every CU reservation and tile configuration (vitmi_set_reserved_cus may change between the query
     // and the call; callers cache the answer per shape)
@@ -600,6 +676,13 @@ extern "C" int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long
     if (dt == VITMI_BF16 && ldc == Q && vitmi_gemm_tn_fast_ok(P, Q, U, ldu, V, ldv, C, ldc)) {
         ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * P * Q * (double)T);
         return vitmi_gemm_tn_fast(P, Q, T, U, ldu, V, ldv, C, ldc, (float*)workspace, s);
+    }
+    if (dt == VITMI_F32) {
+        ProfScope prof(VITMI_FAM_GEMM, s, 2.0 * P * Q * (double)T);
+        F32Operand a{(const float*)U, 1, ldu, P, 0, 0, 0, 0, 0, 0, 0, 0};
+        F32Operand b{(const float*)V, 1, ldv, Q, 0, 0, 0, 0, 0, 0, 0, 0};
+        Epilogue epi{C, ldc, nullptr, nullptr, 0, nullptr, 0, 0, 0};
+        return launch_f32_plain(a, b, epi, P, Q, T, (float*)workspace, s, "vitmi_gemm_wgrad(f32)");
     }
     // general path: the strided GEMM with both operands read along their output index
     return vitmi_gemm(dt, P, Q, T, U, 1, ldu, V, 1, ldv, C, ldc, VITMI_F32, VITMI_EPI_NONE, nullptr, nullptr, 0,
