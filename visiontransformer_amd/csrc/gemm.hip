@@ -315,8 +315,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand 
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kz0; k0 < kz1; k0 += TK) {
-        float av[4], bv[4];
+    // the next tile's elements are requested before the current tile's products are issued
+    float av[4], bv[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = threadIdx.x + i * 256;
@@ -326,6 +327,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand 
             if (b_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
             bv[i] = B.at(n0 + r, k0 + k, kz1);
         }
+    };
+    if (kz0 < kz1) fetch(kz0);
+    for (int k0 = kz0; k0 < kz1; k0 += TK) {
         __syncthreads();  // the previous tile's fragments have been read
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand 
             Bs[r][k] = bv[i];
         }
         __syncthreads();
+        if (k0 + TK < kz1) fetch(k0 + TK);
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 4) {
             const float a0 = As[wm + fr][kk + fk], a1 = As[wm + 16 + fr][kk + fk];
