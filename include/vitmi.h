@@ -258,6 +258,22 @@ long long vitmi_patch_embed_bwd_w_workspace_bytes(int dt, int B, int C, int H, i
 int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, long long dy_batch_stride, float* dw,
                             void* workspace, int dt, int B, int C, int H, int W, int p, int D, void* stream);
 
+/* The same two products for square patches NARROWER than 8 pixels (p in {1, 2, 4}: the 4 x 4 patches of the 32 x 32
+ * geometry, UMAP.py:12-17), bf16 image and bf16 compute, still gathered in place: the product runs over groups of
+ * g = 8 / p horizontally adjacent patches (16 contiguous bytes of an image row) against a block form of the weight.
+ * vitmi_patch_wide_group: g when the form applies to this geometry (W % 8 == 0, D % 8 == 0), else 0.
+ * vitmi_patch_wide_weight: w [D, C*p*p] fp32 (+ bias [D]) -> w_wide [g*D, C*p*8] bf16 (+ bias_wide [g*D] fp32); redo when
+ * the weight changes.  vitmi_patch_embed_fwd_wide / _bwd_w_wide: as the calls above (dw is the ordinary [D, C*p*p]
+ * gradient; the workspace holds the block-form gradient and the token slabs). */
+int vitmi_patch_wide_group(int dt, int x_dt, int B, int C, int H, int W, int p, int D);
+int vitmi_patch_wide_weight(const float* w, const float* bias, void* w_wide, float* bias_wide, int D, int C, int p,
+                            void* stream);
+int vitmi_patch_embed_fwd_wide(const void* x, const void* w_wide, const float* bias_wide, void* out, int B, int C, int H,
+                               int W, int p, int D, long long out_batch_stride, void* stream);
+long long vitmi_patch_embed_bwd_w_wide_workspace_bytes(int B, int C, int H, int W, int p, int D);
+int vitmi_patch_embed_bwd_w_wide(const void* x, const void* dy, float* dw, void* workspace, int B, int C, int H, int W,
+                                 int p, int D, void* stream);
+
 /* seq_ord[i] = i*(1 - m[i]) + m[i]*masked_row for i < n: the index arithmetic of ViT_mask.py:162-163
  * (masked_row = unk_embed_index) in one launch; masked_row = -1 marks "no positional row" for the variants
  * that zero the masked positions (ViT_ape.py:186-190).  unk_mask: n entries of int64 (mask_is_int64 != 0) or

@@ -180,8 +180,14 @@ def test_tokens_gradient_is_deterministic(ops):
 # ------------------------------------------------------------------------------------------ patch embedding
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("img,p,C,D,B", [(32, 4, 3, 96, 3), (64, 16, 3, 128, 2), (224, 16, 3, 64, 1), (24, 8, 1, 40, 2),
-                                           (16, 2, 3, 24, 2)])
+                                           (16, 2, 3, 24, 2), (32, 4, 3, 192, 64), (40, 4, 3, 64, 2), (20, 4, 3, 64, 2),
+                                           (16, 1, 1, 16, 2), (32, 4, 1, 8, 1)])
 def test_patch_embed(ops, dtype, img, p, C, D, B):
+    # patches narrower than 8 pixels in bf16: groups of 8 / p patches read in place (image width a multiple of 8),
+    # else (width 20) the gathered copy
+    from visiontransformer_amd._lib import lib
+    if dtype == torch.bfloat16 and p < 8:
+        assert lib.vitmi_patch_wide_group(1, 1, B, C, img, img, p, D) == (8 // p if img % 8 == 0 else 0)
     x, w, b = rnd(B, C, img, img, seed=1), rnd(D, C, p, p, seed=2, scale=(C * p * p) ** -0.5), rnd(D, seed=3)
     xr = q(x, dtype).requires_grad_(True)
     wr, br = q(w, dtype).requires_grad_(True), b.clone().requires_grad_(True)

@@ -94,6 +94,11 @@ SIGNATURES = {
     "vitmi_patch_embed_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, L, P]),
     "vitmi_patch_embed_bwd_w_workspace_bytes": (L, [I, I, I, I, I, I, I]),
     "vitmi_patch_embed_bwd_w": (I, [P, I, P, L, P, P, I, I, I, I, I, I, I, P]),
+    "vitmi_patch_wide_group": (I, [I, I, I, I, I, I, I, I]),
+    "vitmi_patch_wide_weight": (I, [P, P, P, P, I, I, I, P]),
+    "vitmi_patch_embed_fwd_wide": (I, [P, P, P, P, I, I, I, I, I, I, L, P]),
+    "vitmi_patch_embed_bwd_w_wide_workspace_bytes": (L, [I, I, I, I, I, I]),
+    "vitmi_patch_embed_bwd_w_wide": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "vitmi_tokens_assemble_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
     "vitmi_tokens_assemble_bwd_workspace_bytes": (L, [I, I]),
     "vitmi_tokens_assemble_bwd": (I, [P, P, P, P, I, P, I, I, I, I, P]),

@@ -47,9 +47,9 @@ int vitmi_gemm_nt_fast_planes(int M, int N, int K, const void* A, long long lda,
 bool vitmi_patch_fast_ok(const void* img, const void* w, const void* out, int W, int p, int D, int E,
                          long long out_batch_stride);
 int vitmi_patch_fwd_fast(const void* img, const void* w, const float* bias, void* out, int B, int C, int H, int W,
-                         int p, int D, long long out_batch_stride, hipStream_t s);
+                         int p, int pw, int D, long long out_batch_stride, hipStream_t s);
 int vitmi_patch_bwd_w_fast(const void* img, const void* dy, float* dw, float* slabs, int B, int C, int H, int W, int p,
-                           int D, hipStream_t s);
+                           int pw, int D, hipStream_t s);
 
 namespace {
 
@@ -580,7 +580,7 @@ extern "C" int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, con
     Epilogue epi{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride};
     if (dt == VITMI_BF16 && x_dt == VITMI_BF16 && vitmi_patch_fast_ok(x, w, out, W, p, D, K, out_batch_stride)) {
         ProfScope prof(VITMI_FAM_GEMM_NT_FAST0, s, 2.0 * M * N * K);
-        return vitmi_patch_fwd_fast(x, w, bias, out, B, C, H, W, p, D, out_batch_stride, s);
+        return vitmi_patch_fwd_fast(x, w, bias, out, B, C, H, W, p, p, D, out_batch_stride, s);
     }
     ProfScope prof(VITMI_FAM_GEMM, s, 2.0 * M * N * K);
     if (dt == VITMI_F32) {
@@ -636,7 +636,7 @@ extern "C" int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, 
     Epilogue epi{dw, E, nullptr, nullptr, 0, nullptr, 0, 0, 0};
     if (dt == VITMI_BF16 && x_dt == VITMI_BF16 && vitmi_patch_fast_ok(x, dy, dw, W, p, D, E, 8)) {
         ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * D * E * (double)T);
-        return vitmi_patch_bwd_w_fast(x, dy, dw, (float*)workspace, B, C, H, W, p, D, s);
+        return vitmi_patch_bwd_w_fast(x, dy, dw, (float*)workspace, B, C, H, W, p, p, D, s);
     }
     ProfScope prof(VITMI_FAM_GEMM, s, 2.0 * D * E * (double)T);
     if (dt == VITMI_F32) {
@@ -658,6 +658,100 @@ extern "C" int vitmi_patch_embed_bwd_w(const void* x, int x_dt, const void* dy, 
         return VITMI_ERR_BAD_ARG;
     }
     VITMI_LAUNCH_CHECK("vitmi_patch_embed_bwd_w(bf16)");
+    return VITMI_OK;
+}
+
+// ---- square patches narrower than 8 pixels, in place (the 4 x 4 patches of the 32 x 32 geometry, UMAP.py:12-17) ---------
+// A 16-byte piece of a bf16 image row is 8 pixels = the row pieces of g = 8 / p horizontally adjacent patches.  The
+// product is therefore taken over "wide" patches of p x 8 pixels: row = the group of g consecutive tokens, K = C p 8,
+// N = g D outputs (token s of the group, feature d at column s D + d -- the group's g rows of the [tokens, D] result,
+// which are contiguous), against the block weight Wg[s D + d][c, i, jj] = W[d][c, i, jj - s p] for s p <= jj < (s+1) p,
+// else 0.  g times the arithmetic of a product that is a per-mille of the step, and no gathered copy of the image.
+namespace {
+__global__ void patch_wide_weight_kernel(const float* __restrict__ w, const float* __restrict__ bias, bf16_t* __restrict__ wg,
+                                         float* __restrict__ bias_g, int D, int C, int p) {
+    const int g = 8 / p, K = C * p * 8, total = g * D * K;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int n = i / K, k = i - n * K;
+        const int s = n / D, d = n - s * D;
+        const int c = k / (p * 8), q = k - c * p * 8;
+        const int r = q >> 3, jj = q & 7;
+        const int j = jj - s * p;
+        wg[i] = (j >= 0 && j < p) ? (bf16_t)w[((long long)d * C + c) * p * p + r * p + j] : (bf16_t)0.f;
+    }
+    if (bias && bias_g)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g * D; i += gridDim.x * blockDim.x) bias_g[i] = bias[i % D];
+}
+// dw[d][c, r, j] = sum_s dwg[s D + d][c, r, s p + j]
+__global__ void patch_wide_collapse_kernel(const float* __restrict__ dwg, float* __restrict__ dw, int D, int C, int p) {
+    const int g = 8 / p, E = C * p * p, K = C * p * 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < D * E; i += gridDim.x * blockDim.x) {
+        const int d = i / E, e = i - d * E;
+        const int c = e / (p * p), q = e - c * p * p;
+        const int r = q / p, j = q - r * p;
+        float v = 0.f;
+        for (int s = 0; s < g; ++s) v += dwg[(long long)(s * D + d) * K + c * p * 8 + r * 8 + s * p + j];
+        dw[i] = v;
+    }
+}
+inline bool wide_geometry_ok(int B, int C, int H, int W, int p, int D) {
+    return B > 0 && C > 0 && D > 0 && p > 0 && p < 8 && 8 % p == 0 && H % p == 0 && W % 8 == 0 && D % 8 == 0;
+}
+}  // namespace
+
+extern "C" int vitmi_patch_wide_group(int dt, int x_dt, int B, int C, int H, int W, int p, int D) {
+    return (dt == VITMI_BF16 && x_dt == VITMI_BF16 && wide_geometry_ok(B, C, H, W, p, D)) ? 8 / p : 0;
+}
+
+extern "C" int vitmi_patch_wide_weight(const float* w, const float* bias, void* w_wide, float* bias_wide, int D, int C,
+                                       int p, void* stream) {
+    VITMI_CHECK_ARG(w && w_wide && D > 0 && C > 0 && p > 0 && p < 8 && 8 % p == 0, "vitmi_patch_wide_weight: bad argument");
+    VITMI_CHECK_ARG(!bias == !bias_wide, "vitmi_patch_wide_weight: bias and bias_wide go together");
+    const int total = (8 / p) * D * C * p * 8;
+    hipLaunchKernelGGL(patch_wide_weight_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, as_stream(stream), w, bias,
+                       (bf16_t*)w_wide, bias_wide, D, C, p);
+    VITMI_LAUNCH_CHECK("vitmi_patch_wide_weight");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_patch_embed_fwd_wide(const void* x, const void* w_wide, const float* bias_wide, void* out, int B,
+                                          int C, int H, int W, int p, int D, long long out_batch_stride, void* stream) {
+    VITMI_CHECK_ARG(x && w_wide && out, "vitmi_patch_embed_fwd_wide: null pointer");
+    VITMI_CHECK_ARG(wide_geometry_ok(B, C, H, W, p, D), "vitmi_patch_embed_fwd_wide: bad geometry B=%d C=%d H=%d W=%d p=%d D=%d",
+                    B, C, H, W, p, D);
+    const int g = 8 / p, per = (H / p) * (W / p);
+    VITMI_CHECK_ARG(out_batch_stride >= (long long)per * D && out_batch_stride % 8 == 0 && al16(x) && al16(w_wide) && al16(out),
+                    "vitmi_patch_embed_fwd_wide: operands must be 16-byte aligned, batch stride a multiple of 8");
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_GEMM_NT_FAST0, s, 2.0 * B * per * D * C * p * 8);
+    return vitmi_patch_fwd_fast(x, w_wide, bias_wide, out, B, C, H, W, p, 8, g * D, out_batch_stride, s);
+}
+
+extern "C" long long vitmi_patch_embed_bwd_w_wide_workspace_bytes(int B, int C, int H, int W, int p, int D) {
+    if (!wide_geometry_ok(B, C, H, W, p, D)) return 0;
+    const int g = 8 / p, K = C * p * 8, T = B * (H / p) * (W / 8);
+    const long long dwg = ((long long)g * D * K * (long long)sizeof(float) + 255) & ~255ll;
+    const int ns = vitmi_gemm_tn_slabs_bound(g * D, K, T);
+    return dwg + (ns > 1 ? (long long)ns * g * D * K * (long long)sizeof(float) : 0);
+}
+
+extern "C" int vitmi_patch_embed_bwd_w_wide(const void* x, const void* dy, float* dw, void* workspace, int B, int C, int H,
+                                            int W, int p, int D, void* stream) {
+    VITMI_CHECK_ARG(x && dy && dw && workspace, "vitmi_patch_embed_bwd_w_wide: null pointer");
+    VITMI_CHECK_ARG(wide_geometry_ok(B, C, H, W, p, D) && al16(x) && al16(dy), "vitmi_patch_embed_bwd_w_wide: bad geometry");
+    const int g = 8 / p, K = C * p * 8;
+    const long long dwg_bytes = ((long long)g * D * K * (long long)sizeof(float) + 255) & ~255ll;
+    float* dwg = (float*)workspace;
+    float* slabs = (float*)((char*)workspace + dwg_bytes);
+    hipStream_t s = as_stream(stream);
+    {
+        ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, 2.0 * g * D * K * (double)B * (H / p) * (W / 8));
+        // dy [tokens, D] read as [groups, g D]: the g tokens of a group are consecutive rows
+        const int rc = vitmi_patch_bwd_w_fast(x, dy, dwg, slabs, B, C, H, W, p, 8, g * D, s);
+        if (rc != VITMI_OK) return rc;
+    }
+    hipLaunchKernelGGL(patch_wide_collapse_kernel, dim3(ceil_div(D * C * p * p, 256)), dim3(256), 0, s, dwg, dw, D, C, p);
+    VITMI_LAUNCH_CHECK("vitmi_patch_embed_bwd_w_wide");
     return VITMI_OK;
 }
 

@@ -61,18 +61,21 @@ __device__ __forceinline__ void stage_nt(const bf16_t* __restrict__ g, long long
 }
 
 // Patch operand: logical matrix P[token m][element e], m = (image b, gy, gx), e = (c, i, j), read in
-// place from the NCHW image: P = x[b, c, gy*ps + i, gx*ps + j].  With ps % 8 == 0 a 16-byte chunk
-// (8 elements) never leaves one patch row, so it is 16 contiguous bytes of the image.
+// place from the NCHW image: P = x[b, c, gy*ps + i, gx*pw + j], patches ps rows high and pw pixels wide.  With
+// pw % 8 == 0 a 16-byte chunk (8 elements) never leaves one patch row, so it is 16 contiguous bytes of the image.
+// Square patches narrower than 8 pixels (the 4 x 4 patches of the 32-pixel geometry) are read as "wide" patches:
+// pw = 8 spans 8 / ps horizontally adjacent patches, the row of the product is that group of tokens and the weight
+// is the block form vitmi_patch_wide_weight builds.
 struct PatchGeom {
-    int C, H, W, ps, gw, per;  // per = patches per image
-    int tokens, elems;         // B*per, C*ps*ps
+    int C, H, W, ps, pw, gw, per;  // gw = (wide) patches per image row, per = per image
+    int tokens, elems;             // B*per, C*ps*pw
 };
 __device__ __forceinline__ long long patch_addr(const PatchGeom& g, int m, int e) {
     const int b = m / g.per, t = m - b * g.per;
     const int gy = t / g.gw, gx = t - gy * g.gw;
-    const int c = e / (g.ps * g.ps), q = e - c * g.ps * g.ps;
-    const int i = q / g.ps, j = q - i * g.ps;
-    return (((long long)b * g.C + c) * g.H + (gy * g.ps + i)) * g.W + gx * g.ps + j;
+    const int c = e / (g.ps * g.pw), q = e - c * g.ps * g.pw;
+    const int i = q / g.pw, j = q - i * g.pw;
+    return (((long long)b * g.C + c) * g.H + (gy * g.ps + i)) * g.W + gx * g.pw + j;
 }
 
 template <int ROWS, int NW>
@@ -1693,10 +1696,12 @@ bool vitmi_patch_fast_ok(const void* img, const void* w, const void* out, int W,
            al16(w) && al16(out);
 }
 
+// pw = p for patches whose width is a multiple of 8; pw = 8 > p for the wide form, where D counts the features of
+// the whole group (8 / p tokens) and w / bias are the block forms
 int vitmi_patch_fwd_fast(const void* img, const void* w, const float* bias, void* out, int B, int C, int H, int W,
-                         int p, int D, long long out_batch_stride, hipStream_t s) {
-    const int gh = H / p, gw = W / p, per = gh * gw, E = C * p * p;
-    PatchGeom pg{C, H, W, p, gw, per, B * per, E};
+                         int p, int pw, int D, long long out_batch_stride, hipStream_t s) {
+    const int gh = H / p, gw = W / pw, per = gh * gw, E = C * p * pw;
+    PatchGeom pg{C, H, W, p, pw, gw, per, B * per, E};
     FastEpi e{out, D, bias, nullptr, 0, nullptr, 0, per, out_batch_stride, nullptr, nullptr, nullptr, nullptr, 0, 0};
     return launch_nt_fast<true>(B * per, D, E, img, 0, w, E, e, VITMI_BF16, VITMI_EPI_NONE, pg, s);
 }
@@ -1996,9 +2001,9 @@ int vitmi_gemm_tn_batch(int n, const int* P, const int* Q, int T, const void* co
 
 // patch-embedding weight gradient on a bf16 image: dW[d][e] = sum_t dy[t][d] * P[t][e]
 int vitmi_patch_bwd_w_fast(const void* img, const void* dy, float* dw, float* slabs, int B, int C, int H, int W, int p,
-                           int D, hipStream_t s) {
-    const int gh = H / p, gw = W / p, per = gh * gw, E = C * p * p;
-    PatchGeom pg{C, H, W, p, gw, per, B * per, E};
+                           int pw, int D, hipStream_t s) {
+    const int gh = H / p, gw = W / pw, per = gh * gw, E = C * p * pw;
+    PatchGeom pg{C, H, W, p, pw, gw, per, B * per, E};
     return launch_tn_fast<true>(D, E, B * per, dy, D, img, 0, dw, E, slabs, pg, s);
 }
 

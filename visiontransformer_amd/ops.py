@@ -250,6 +250,26 @@ def refresh_pinned_copies(pinned):
         _cache_store(key, p, copy)
 
 
+def patch_wide_weight(weight, bias, g):
+    """(block weight [g*D, C*p*8] bf16, block bias [g*D] fp32 or None) of vitmi_patch_wide_weight for a Conv2d weight
+    [D, C, p, p] with p < 8, cached like the folded operands (until a parameter changes or drop_folded() is called)."""
+    parts = [t for t in (weight, bias) if t is not None]
+    key = ("wide", id(weight), id(bias))
+    stamp = tuple((t._version, t.data_ptr()) for t in parts)
+    hit = _fold_cache.get(key)
+    if hit is not None and hit[0] == stamp and all(r() is t for r, t in zip(hit[1], parts)):
+        return hit[2]
+    D, C, p, _ = weight.shape
+    w32 = weight.detach().float().contiguous()
+    b32 = bias.detach().float().contiguous() if bias is not None else None
+    w_wide = torch.empty((g * D, C * p * 8), dtype=torch.bfloat16, device=weight.device)
+    b_wide = torch.empty(g * D, dtype=torch.float32, device=weight.device) if bias is not None else None
+    check(lib.vitmi_patch_wide_weight(_p(w32), _p(b32), _p(w_wide), _p(b_wide), D, C, p, _stream()),
+          "vitmi_patch_wide_weight")
+    _fold_cache[key] = (stamp, [weakref.ref(t) for t in parts], (w_wide, b_wide))
+    return w_wide, b_wide
+
+
 def clear_cast_cache():
     """Drop every cached compute copy (call after parameters were changed behind autograd's back,
     e.g. by the fused optimizer kernel)."""
@@ -734,9 +754,10 @@ def _as2d(x):
 class PatchEmbedFn(torch.autograd.Function):
     """Conv2d(k=s=p)+bias then flatten/transpose (mymodel/ViT.py:33,43) -> [B, tokens, D].
 
-    Patch sizes that are multiples of 8 are gathered in place by the GEMM's direct-to-LDS loads;
-    others (the 4x4 patches of the CIFAR geometry) are gathered once into a [tokens, C*p*p] matrix
-    that the ordinary GEMMs then read."""
+    The patches are gathered in place by the GEMM's loads: multiples of 8 pixels as they are, the 4 x 4 patches of
+    the 32-pixel geometry as groups of two adjacent patches against a block form of the weight
+    (vitmi_patch_embed_fwd_wide), fp32 compute through the strided fp32 kernel.  Only geometries none of these
+    covers (an image width that is not a multiple of 8 in bf16) go through a gathered [tokens, C*p*p] copy."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, cdt):
@@ -753,8 +774,21 @@ class PatchEmbedFn(torch.autograd.Function):
         ctx.geom = (B, C, H, W, p, per)
         ctx.cdt = cdt
         ctx.has_bias = bias is not None
+        wide = 0
+        if cdt == torch.bfloat16 and not (p % 8 == 0 and W % 8 == 0):
+            wide = int(lib.vitmi_patch_wide_group(_dt(cdt), _dt(cdt), B, C, H, W, p, D))
+        ctx.wide = wide
+        if wide:
+            x = cast(x, torch.bfloat16)
+            w_wide, b_wide = patch_wide_weight(weight, bias, wide)
+            out = torch.empty((B, per, D), dtype=cdt, device=x.device)
+            check(lib.vitmi_patch_embed_fwd_wide(_p(x), _p(w_wide), _p(b_wide), _p(out), B, C, H, W, p, D, per * D,
+                                                 _stream()), "vitmi_patch_embed_fwd_wide")
+            ctx.in_place = True
+            ctx.save_for_backward(x, weight)
+            return out
         w_c = compute_copy(weight, cdt).view(D, C * p * p)
-        in_place = p % 8 == 0 and W % 8 == 0
+        in_place = (p % 8 == 0 and W % 8 == 0) or cdt == torch.float32
         ctx.in_place = in_place
         if in_place:
             if cdt == torch.bfloat16 and x.dtype != torch.bfloat16:
@@ -800,7 +834,12 @@ class PatchEmbedFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 raise NotImplementedError("per-sample norms with a gradient into the images")
             return None, None, None, None
-        if ctx.in_place:
+        if ctx.wide:
+            dw = torch.empty((D, C * p * p), dtype=torch.float32, device=x.device)
+            ws = _ws(lib.vitmi_patch_embed_bwd_w_wide_workspace_bytes(B, C, H, W, p, D), x.device)
+            check(lib.vitmi_patch_embed_bwd_w_wide(_p(x), _p(dy), _p(dw), _p(ws), B, C, H, W, p, D, _stream()),
+                  "vitmi_patch_embed_bwd_w_wide")
+        elif ctx.in_place:
             dw = torch.empty((D, C * p * p), dtype=torch.float32, device=x.device)
             ws = _ws(lib.vitmi_patch_embed_bwd_w_workspace_bytes(_dt(dy), B, C, H, W, p, D), x.device)
             check(lib.vitmi_patch_embed_bwd_w(_p(x), _dt(x), _p(dy), per * D, _p(dw), _p(ws), _dt(dy), B, C, H, W, p,
