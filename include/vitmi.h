@@ -368,13 +368,15 @@ int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const voi
                        float* dw1, float* db1, float* dw2, float* db2, void* workspace, void* stream);
 /* At the small geometry (bf16, D <= 256 and a multiple of 32, hidden width a multiple of 32, 16-byte aligned
  * operands) the block calls run as one-launch kernels that keep the sub-block's activations in LDS; same outputs to the
- * bf16 bar.  vitmi_debug_set_small_fused(mask): bit 0 = the MLP sub-block's forward (default all bits set);
+ * bf16 bar.  vitmi_debug_set_small_fused(mask): bit 0 = the MLP sub-block's forward, bit 1 = the attention
+ * sub-block's forward (up to 96 tokens, heads of 8 or 16, no probability export; default both);
  * process-wide, for benchmarking and for the tests that compare the two forms. */
 int vitmi_debug_set_small_fused(int mask);
 /* The two weight-gradient products of a sub-block's backward call may run on a second stream of the library's own,
  * beside the input-gradient chain (forked from and joined back into the caller's stream inside the call; their scratch
- * is a region of its own in the workspace).  mode -1: automatic, for rows * D up to 8 M elements (default); 0: never;
- * 1: always.  Process-wide, for benchmarking. */
+ * is a region of its own in the workspace).  mode -1: automatic (default) = for rows * D up to 8 M elements while the
+ * caller's stream is being captured into a graph (issued eagerly the event calls cost the host more than the overlap
+ * returns); 0: never; 1: always.  Process-wide, for benchmarking. */
 int vitmi_debug_set_wgrad_overlap(int mode);
 int vitmi_attn_block_fwd(int dt, int B, int N, int D, int H, int DH, const void* x, const float* gamma, const float* beta,
                          float eps, const void* w_qkv, const float* b_qkv, const void* w_out, const float* b_out,

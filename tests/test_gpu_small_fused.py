@@ -106,3 +106,56 @@ def test_model_step_with_and_without_the_one_launch_kernels():
     assert rel_err(logits, ref_logits) < 2e-2
     for k in ref:
         assert rel_err(grads[k], ref[k]) < 2e-2, k
+
+
+def _attn_block(B, N, D, H, DH, fused, qkv_bias, seed=0):
+    from visiontransformer_amd._lib import check, lib
+    from visiontransformer_amd.ops import _p, _stream
+    I = H * DH
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B * N, D, generator=g).to(DEV, BF)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(D, generator=g)).to(DEV)
+    wq = (torch.randn(3 * I, D, generator=g) * D ** -0.5).to(DEV, BF)
+    bq = (0.1 * torch.randn(3 * I, generator=g)).to(DEV) if qkv_bias else None
+    wo = (torch.randn(D, I, generator=g) * I ** -0.5).to(DEV, BF)
+    bo = (0.1 * torch.randn(D, generator=g)).to(DEV)
+    out = dict(xn=torch.empty(B * N, D, dtype=BF, device=DEV), mean=torch.empty(B * N, device=DEV),
+               rstd=torch.empty(B * N, device=DEV), qkv=torch.empty(B * N, 3 * I, dtype=BF, device=DEV),
+               o=torch.empty(B * N, I, dtype=BF, device=DEV), lse=torch.empty(B, H, N, device=DEV),
+               y=torch.empty(B * N, D, dtype=BF, device=DEV))
+    check(lib.vitmi_debug_set_small_fused(-1 if fused else 0))
+    try:
+        check(lib.vitmi_attn_block_fwd(1, B, N, D, H, DH, _p(x), _p(gamma), _p(beta), 1e-5, _p(wq), _p(bq), _p(wo), _p(bo),
+                                       _p(out["xn"]), _p(out["mean"]), _p(out["rstd"]), _p(out["qkv"]), _p(out["o"]),
+                                       _p(out["lse"]), None, _p(out["y"]), 0, _stream()), "vitmi_attn_block_fwd")
+        torch.cuda.synchronize()
+    finally:
+        check(lib.vitmi_debug_set_small_fused(-1))
+    return dict(x=x, gamma=gamma, beta=beta, wq=wq, bq=bq, wo=wo, bo=bo), out
+
+
+@pytest.mark.parametrize("qkv_bias", [False, True])
+@pytest.mark.parametrize("B,N,D,H,DH", [(256, 65, 192, 12, 8), (4, 33, 192, 12, 8), (3, 17, 64, 4, 8), (2, 96, 256, 16, 16),
+                                        (2, 50, 128, 4, 16), (5, 1, 64, 4, 8), (2, 81, 96, 4, 8)])
+def test_attention_block_forward_one_launch_against_steps_and_fp64(B, N, D, H, DH, qkv_bias):
+    ins, fused = _attn_block(B, N, D, H, DH, True, qkv_bias)
+    _, steps = _attn_block(B, N, D, H, DH, False, qkv_bias)
+    for k in ("mean", "rstd"):
+        assert rel_err(fused[k], steps[k]) < 1e-6, k
+    for k in ("xn", "qkv", "o", "y"):
+        assert rel_err(fused[k].float(), steps[k].float()) < 8e-3, k
+    assert rel_err(fused["lse"], steps["lse"]) < 2e-2
+    # fp64 evaluation from the same bf16 operands (rounded where the kernels round)
+    I = H * DH
+    x = ins["x"].double()
+    xn = torch.nn.functional.layer_norm(x, (D,), ins["gamma"].double(), ins["beta"].double(), 1e-5)
+    qkv = xn.to(BF).double() @ ins["wq"].double().t() + (ins["bq"].double() if qkv_bias else 0)
+    q_, k_, v_ = (t.reshape(B, N, H, DH).permute(0, 2, 1, 3) for t in qkv.to(BF).double().split(I, dim=-1))
+    dots = (q_ @ k_.transpose(-1, -2)) * DH ** -0.5
+    o = (torch.softmax(dots, -1) @ v_).permute(0, 2, 1, 3).reshape(B * N, I)
+    y = o.to(BF).double() @ ins["wo"].double().t() + ins["bo"].double() + x
+    assert rel_err(fused["qkv"].double(), qkv) < 2e-2
+    assert rel_err(fused["o"].double(), o) < 2e-2
+    assert rel_err(fused["lse"].double(), torch.logsumexp(dots, -1)) < 2e-2
+    assert rel_err(fused["y"].double(), y) < 2e-2

@@ -58,6 +58,31 @@ def ff(rows, D, M):
     check(lib.vitmi_debug_set_small_fused(-1))
 
 
+def attn(B, N, D, H, DH):
+    I = H * DH
+    x = torch.randn(B * N, D, device=DEV).to(BF)
+    gamma, beta = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    wq = (torch.randn(3 * I, D, device=DEV) * D ** -0.5).to(BF)
+    wo = (torch.randn(D, I, device=DEV) * I ** -0.5).to(BF)
+    bo = torch.zeros(D, device=DEV)
+    xn, y = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(B * N, device=DEV), torch.empty(B * N, device=DEV)
+    qkv = torch.empty(B * N, 3 * I, dtype=BF, device=DEV)
+    o = torch.empty(B * N, I, dtype=BF, device=DEV)
+    lse = torch.empty(B, H, N, device=DEV)
+
+    def run():
+        check(lib.vitmi_attn_block_fwd(1, B, N, D, H, DH, _p(x), _p(gamma), _p(beta), 1e-5, _p(wq), None, _p(wo), _p(bo),
+                                       _p(xn), _p(mean), _p(rstd), _p(qkv), _p(o), _p(lse), None, _p(y), 0, _stream()))
+    out = []
+    for mask in (0, 3):
+        check(lib.vitmi_debug_set_small_fused(mask))
+        out.append(timeit(run))
+    check(lib.vitmi_debug_set_small_fused(-1))
+    print(f"attention fwd B {B} N {N} D {D} H {H} dh {DH}: steps {out[0]:.1f} us, one launch {out[1]:.1f} us")
+
+
 if __name__ == "__main__":
     for B in (256, 64):
         ff(B * 65, 192, 512)
+        attn(B, 65, 192, 12, 8)

@@ -23,6 +23,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "small.h"
 
 int vitmi_reserved_cus();   // gemm_fast.hip
 
@@ -204,7 +205,10 @@ __host__ __device__ __forceinline__ int export_tile_elems(int N) { return (16 * 
 template <int DH, int NC, bool EXPORT>
 __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs, const bf16x8 (&qf)[AttnDims<DH>::KS], int qt,
                                               int b, int h, int N, int H, float scale, bf16_t* __restrict__ out,
-                                              float* __restrict__ lse, bf16_t* __restrict__ probs, bf16_t* Pw, int lane) {
+                                              float* __restrict__ lse, bf16_t* __restrict__ probs, bf16_t* Pw, int lane,
+                                              bf16_t* o_lds = nullptr, int o_ld = 0) {
+    // o_lds: also leave the tile's output rows in LDS, [row of the image][H * DH] with o_ld elements per row (the
+    // one-launch sub-block kernel multiplies them by the projection weight without a round trip through HBM)
     using A = AttnDims<DH>;
     const int fr = lane & 15, fg = lane >> 4;
     const int I = H * DH;
@@ -320,6 +324,7 @@ __device__ __forceinline__ void attn_fwd_tile(const bf16_t* Ks, const bf16_t* Vs
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pk[r] = (bf16_t)(o[dt][r] * inv);
                 *reinterpret_cast<bf16x4*>(orow + d) = pk;
+                if (o_lds) *reinterpret_cast<bf16x4*>(o_lds + q * o_ld + h * DH + d) = pk;
             }
         }
     }
@@ -370,6 +375,131 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(NC <= 8
         for (int ks = 0; ks < A::KS; ++ks) qf[ks] = qnext[ks];
         load_q(t + nwaves);                           // the next tile's queries load under this tile's arithmetic
         attn_fwd_tile<DH, NC, EXPORT>(Ks + hh * IMG, Vs + hh * IMG, qf, qt, b, h0 + hh, N, H, scale, out, lse, probs, Pw, lane);
+    }
+}
+
+// ================================================================ attention sub-block forward in one launch (small geometry)
+// y = x + Wo softmax(q k^T / sqrt(dh)) v + bo with (q, k, v) = Wqkv LN(x) (+ bqkv), mymodel/ViT.py:52-58, 77-104, 119, for
+// sequences of up to 96 tokens of width up to 256 with heads of 8 or 16: one workgroup per image.  The image's rows are
+// normalised into LDS; the qkv product (weights streamed from L2, small.h) lands, 16 bytes = one lane's 8 features at a
+// time, directly in the per-head q / k / v LDS images that attn_fwd_tile reads (a lane's 8 consecutive features are
+// one 16-byte chunk of one head's row); the softmax tiles leave their output rows in LDS for the output projection.
+// Written out: what the backward pass reads (LN(x) and its statistics, qkv rows, the attention output, the row
+// log-sum-exps) and y.
+struct AttnSmallArgs {
+    const bf16_t* x;
+    const float *gamma, *beta;
+    const bf16_t* w_qkv;
+    const float* b_qkv;
+    const bf16_t* w_out;
+    const float* b_out;
+    bf16_t *xn, *qkv, *o, *y;
+    float *mean, *rstd, *lse;
+    int N, D, H;
+    float eps;
+};
+
+template <int DH, int NC, int MT>
+__global__ __launch_bounds__(SM_THREADS) void attn_small_fwd_kernel(AttnSmallArgs a) {
+    constexpr int NP = NC * 32, IMG = NP * DH, R = MT * 16;
+    static_assert(R <= NP, "the row strip must fit the images");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = a.N, D = a.D, H = a.H, I = H * DH, ldx = D + SM_PAD, ldo = I + SM_PAD;
+    bf16_t* xs = reinterpret_cast<bf16_t*>(smem);   // [R][ldx] normalised rows
+    bf16_t* imgs = xs + R * ldx;                    // [3][H][NP][DH] q, k, v images (+ one row of slack)
+    bf16_t* os = imgs + 3 * H * IMG + 8;            // [R][ldo] attention output rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const long long row0 = (long long)b * N;
+    strip_layernorm<MT>(a.x, a.gamma, a.beta, a.xn, a.mean, a.rstd, row0, N, D, a.eps, xs, ldx);
+    // image rows the product below does not write (R .. NP) and the slack row: zero keys / values
+    {
+        const bf16x8 z = zero8();
+        constexpr int CPR = DH / 8;
+        const int extra = (NP - R) * CPR;
+        for (int i = threadIdx.x; i < 3 * H * extra; i += SM_THREADS) {
+            const int img = i / extra, rem = i - img * extra;
+            *reinterpret_cast<bf16x8*>(imgs + img * IMG + R * DH + rem * 8) = z;
+        }
+        if (threadIdx.x == 0) *reinterpret_cast<bf16x8*>(imgs + 3 * H * IMG) = z;
+    }
+    __syncthreads();
+    const int tok = lane & 15, f8 = (lane >> 4) * 8;
+    // (q, k, v) rows: 32 features per wave and pass, 8 consecutive ones per lane
+    for (int p = wave; p < 3 * I / 32; p += SM_WAVES) {
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rows_gemm<MT, 2, 3>(a.w_qkv, D, p * 32, D / 32, xs, ldx, lane, acc);
+        const int n = p * 32 + f8;
+        f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
+        if (a.b_qkv) {
+            bias0 = *reinterpret_cast<const f32x4*>(a.b_qkv + n);
+            bias1 = *reinterpret_cast<const f32x4*>(a.b_qkv + n + 4);
+        }
+        const int which = n / I, rem = n - which * I, h = rem / DH, d0 = rem - h * DH;
+        bf16_t* img = imgs + (which * H + h) * IMG;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok;
+            bf16x8 v;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                v[t] = r < N ? (bf16_t)(acc[t >> 2][m][t & 3] + (t < 4 ? bias0[t & 3] : bias1[t & 3])) : (bf16_t)0.f;
+            *reinterpret_cast<bf16x8*>(img + img_off<DH>(r, d0 >> 3)) = v;
+            if (r < N) *reinterpret_cast<bf16x8*>(a.qkv + (row0 + r) * 3 * I + n) = v;
+        }
+    }
+    __syncthreads();
+    // softmax tiles: (head, 16 queries) pairs over the waves
+    {
+        using A = AttnDims<DH>;
+        const int fr = lane & 15, fg = lane >> 4;
+        const int ntq = (N + 15) >> 4;
+        const float scale = 1.0f / sqrtf((float)DH);
+        for (int t = wave; t < H * ntq; t += SM_WAVES) {
+            const int h = t / ntq, qt = t - h * ntq;
+            bf16x8 qf[A::KS];
+#pragma unroll
+            for (int ks = 0; ks < A::KS; ++ks) qf[ks] = row_frag<DH>(imgs + h * IMG, qt * 16 + fr, ks, fg);
+            attn_fwd_tile<DH, NC, false>(imgs + (H + h) * IMG, imgs + (2 * H + h) * IMG, qf, qt, b, h, N, H, scale, a.o, a.lse,
+                                         nullptr, nullptr, lane, os, ldo);
+        }
+    }
+    __syncthreads();
+    // y = o Wo^T + bo + x
+    for (int p = wave; p < D / 32; p += SM_WAVES) {
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int n = p * 32 + f8;
+        bf16x8 res[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok < N ? m * 16 + tok : 0;
+            res[m] = *reinterpret_cast<const bf16x8*>(a.x + (row0 + r) * D + n);
+        }
+        rows_gemm<MT, 2, 3>(a.w_out, I, p * 32, I / 32, os, ldo, lane, acc);
+        f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias0;
+        if (a.b_out) {
+            bias0 = *reinterpret_cast<const f32x4*>(a.b_out + n);
+            bias1 = *reinterpret_cast<const f32x4*>(a.b_out + n + 4);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok;
+            if (r < N) {
+                bf16x8 o;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    o[t] = (bf16_t)((acc[t >> 2][m][t & 3] + (t < 4 ? bias0[t & 3] : bias1[t & 3])) + (float)res[m][t]);
+                *reinterpret_cast<bf16x8*>(a.y + (row0 + r) * D + n) = o;
+            }
+        }
     }
 }
 
@@ -1841,4 +1971,56 @@ extern "C" int vitmi_attn_bwd(const void* qkv, const void* out, const void* dout
     rc = attn_bwd_from_dprobs(qkv, lse, dprobs, tmp, S, dS, dt, B, N, H, DH, stream);
     if (rc != VITMI_OK) return rc;
     return vitmi_add(dqkv, tmp, dqkv, dt, (long long)B * N * 3 * H * DH, stream);
+}
+
+// ---------------------------------------------------------------- one-launch attention sub-block forward (small geometry)
+namespace {
+size_t attn_small_lds(int D, int H, int DH, int NC, int MT) {
+    return ((size_t)MT * 16 * (D + SM_PAD) + (size_t)3 * H * NC * 32 * DH + 8 + (size_t)MT * 16 * (H * DH + SM_PAD)) * sizeof(bf16_t);
+}
+template <int DH, int NC, int MT>
+int launch_attn_small(const AttnSmallArgs& a, int B, hipStream_t s) {
+    static unsigned long long done = 0;
+    const size_t lds = attn_small_lds(a.D, a.H, DH, NC, MT);
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_small_fwd_kernel<DH, NC, MT>), LDS_BYTES, &done,
+                        "vitmi_attn_block_fwd: LDS attribute");
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL((attn_small_fwd_kernel<DH, NC, MT>), dim3(B), dim3(SM_THREADS), lds, s, a);
+    VITMI_LAUNCH_CHECK("attn_small_fwd_kernel");
+    return VITMI_OK;
+}
+template <int DH>
+int dispatch_attn_small(const AttnSmallArgs& a, int B, hipStream_t s) {
+    const int mt = (a.N + 15) / 16;
+    if (mt <= 2) return launch_attn_small<DH, 1, 2>(a, B, s);
+    if (mt == 3) return launch_attn_small<DH, 2, 3>(a, B, s);
+    if (mt == 4) return launch_attn_small<DH, 2, 4>(a, B, s);
+    if (mt == 5) return launch_attn_small<DH, 3, 5>(a, B, s);
+    return launch_attn_small<DH, 3, 6>(a, B, s);
+}
+inline bool al16p(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+}  // namespace
+
+// whether vitmi_attn_block_fwd may run as the one-launch kernel (shape part; the operands' alignment is checked at the call)
+bool vitmi_attn_small_ok(int dt, int B, int N, int D, int H, int DH) {
+    if (dt != VITMI_BF16 || B <= 0 || N <= 0 || N > 96) return false;
+    if (DH != 8 && DH != 16) return false;
+    const int I = H * DH;
+    if (D < 32 || D > 256 || D % 32 != 0 || I % 32 != 0 || I > 256) return false;
+    const int mt = (N + 15) / 16 < 2 ? 2 : (N + 15) / 16;
+    return attn_small_lds(D, H, DH, (mt + 1) / 2, mt) <= LDS_BYTES;
+}
+
+// returns 1000 (nothing enqueued) when an operand is not 16-byte aligned
+int vitmi_attn_small_fwd(int B, int N, int D, int H, int DH, const void* x, const float* gamma, const float* beta, float eps,
+                         const void* w_qkv, const float* b_qkv, const void* w_out, const float* b_out, void* xn, float* mean,
+                         float* rstd, void* qkv, void* o, float* lse, void* y, void* stream) {
+    if (!(al16p(x) && al16p(gamma) && al16p(beta) && al16p(w_qkv) && al16p(b_qkv) && al16p(w_out) && al16p(b_out) && al16p(xn) &&
+          al16p(qkv) && al16p(o) && al16p(y)))
+        return 1000;
+    AttnSmallArgs a{(const bf16_t*)x, gamma, beta, (const bf16_t*)w_qkv, b_qkv, (const bf16_t*)w_out, b_out, (bf16_t*)xn,
+                    (bf16_t*)qkv, (bf16_t*)o, (bf16_t*)y, mean, rstd, lse, N, D, H, eps};
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_ATTN_FWD, s, 4.0 * B * H * (double)N * N * DH);
+    return DH == 8 ? dispatch_attn_small<8>(a, B, s) : dispatch_attn_small<16>(a, B, s);
 }

@@ -67,10 +67,22 @@ Side* side_stream() {
     return &sd;
 }
 
-// rows * width up to 8 M elements: every product of the sub-block is then a sub-wave-per-CU launch of ~10 us
-Side* overlap_side(long long rows, int D) {
+// Automatic mode: rows * width up to 8 M elements (every product of the sub-block is then a launch of ~10 us that
+// leaves most of the chip idle) AND the caller's stream is being captured into a graph.  Issued eagerly, each fork /
+// join pair costs the host about 20 us of event calls -- more than the overlap returns -- while in a captured graph
+// they are edges that cost nothing at replay (measured at the 32-pixel geometry, batch 256: eager 3.9 -> 5.3 ms per
+// step with the forks, graph 3.9 -> 3.3 ms).
+Side* overlap_side(long long rows, int D, void* stream) {
     if (g_overlap == 0) return nullptr;
-    if (g_overlap < 0 && rows * (long long)D > (8ll << 20)) return nullptr;
+    if (g_overlap < 0) {
+        if (rows * (long long)D > (8ll << 20)) return nullptr;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(as_stream(stream), &st) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        if (st != hipStreamCaptureStatusActive) return nullptr;
+    }
     return side_stream();
 }
 
@@ -154,7 +166,7 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
     void* dxn = ws + align256((long long)rows * M * esize(dt));
     void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
     void* wg_scratch = (char*)scratch + ff_chain_scratch(rows, D, M);
-    Side* sd = overlap_side(rows, D);
+    Side* sd = overlap_side(rows, D, stream);
     if (sd) {
         STEP(side_fork(sd, stream));
         STEP(vitmi_gemm_wgrad(dt, D, M, rows, dy, D, h, M, dw2, M, wg_scratch, sd->s));
@@ -175,6 +187,11 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
 }
 
 // ------------------------------------------------------------------------------------------- attention block
+bool vitmi_attn_small_ok(int dt, int B, int N, int D, int H, int DH);
+int vitmi_attn_small_fwd(int B, int N, int D, int H, int DH, const void* x, const float* gamma, const float* beta, float eps,
+                         const void* w_qkv, const float* b_qkv, const void* w_out, const float* b_out, void* xn, float* mean,
+                         float* rstd, void* qkv, void* o, float* lse, void* y, void* stream);
+int vitmi_small_fused_mask();
 bool vitmi_qkv_planes_ok(int dt, int B, int N, int D, int H, int DH, const void* x, const void* w_qkv, const void* qkv);
 int vitmi_gemm_to_planes(int T, int N, int K, const void* xn, const void* w, const float* bias, void* planes, void* stream);
 int vitmi_gemm_from_planes(int T, int D, int I3, const void* dqkv_planes, const void* w_t, void* dxn, void* stream);
@@ -206,6 +223,11 @@ extern "C" int vitmi_attn_block_fwd(int dt, int B, int N, int D, int H, int DH, 
     VITMI_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && DH > 0, "vitmi_attn_block_fwd: bad shape");
     VITMI_CHECK_ARG(qkv_layout == 0 || qkv_layout == VITMI_QKV_HEAD_MAJOR, "vitmi_attn_block_fwd: bad qkv layout %d", qkv_layout);
     const int rows = B * N, I = H * DH;
+    if (!probs && !qkv_layout && (vitmi_small_fused_mask() & 2) && vitmi_attn_small_ok(dt, B, N, D, H, DH)) {
+        const int rc = vitmi_attn_small_fwd(B, N, D, H, DH, x, gamma, beta, eps, w_qkv, b_qkv, w_out, b_out, xn, mean, rstd, qkv,
+                                            o, lse, y, stream);
+        if (rc != VITMI_SMALL_NOT_TAKEN) return rc;
+    }
     STEP(vitmi_layernorm_fwd(x, D, gamma, beta, xn, mean, rstd, dt, rows, D, eps, stream));
     if (qkv_layout) {
         if (!vitmi_qkv_planes_ok(dt, B, N, D, H, DH, xn, w_qkv, qkv)) {
@@ -259,7 +281,7 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
     // dqkv lives in the workspace, so its layout is this call's own choice: planes when the three consumers below can
     // read them (a qkv bias wants the column sums of the row-major matrix; the input gradient wants the transposed weight)
     const bool dq_planes = (g_qkv_planes & 2) && !db_qkv && w_qkv_t && vitmi_qkv_planes_ok(dt, B, N, D, H, DH, xn, w_qkv_t, dqkv);
-    Side* sd = dq_planes ? nullptr : overlap_side(rows, D);  // (planes: heads of 64, never a small shape)
+    Side* sd = dq_planes ? nullptr : overlap_side(rows, D, stream);  // (planes: heads of 64, never a small shape)
     if (sd) {
         STEP(side_fork(sd, stream));
         STEP(vitmi_gemm_wgrad(dt, D, I, rows, dy, D, o, I, dw_out, I, wg_scratch, sd->s));

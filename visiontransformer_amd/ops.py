@@ -252,13 +252,8 @@ def refresh_pinned_copies(pinned):
 
 def patch_wide_weight(weight, bias, g):
     """(block weight [g*D, C*p*8] bf16, block bias [g*D] fp32 or None) of vitmi_patch_wide_weight for a Conv2d weight
-    [D, C, p, p] with p < 8, cached like the folded operands (until a parameter changes or drop_folded() is called)."""
-    parts = [t for t in (weight, bias) if t is not None]
-    key = ("wide", id(weight), id(bias))
-    stamp = tuple((t._version, t.data_ptr()) for t in parts)
-    hit = _fold_cache.get(key)
-    if hit is not None and hit[0] == stamp and all(r() is t for r, t in zip(hit[1], parts)):
-        return hit[2]
+    [D, C, p, p] with p < 8.  Built on every call (one launch over 74 KB at the 32-pixel geometry): a cached copy would
+    go stale inside a captured graph, whose replays see the parameters the optimizer updates in place."""
     D, C, p, _ = weight.shape
     w32 = weight.detach().float().contiguous()
     b32 = bias.detach().float().contiguous() if bias is not None else None
@@ -266,7 +261,6 @@ def patch_wide_weight(weight, bias, g):
     b_wide = torch.empty(g * D, dtype=torch.float32, device=weight.device) if bias is not None else None
     check(lib.vitmi_patch_wide_weight(_p(w32), _p(b32), _p(w_wide), _p(b_wide), D, C, p, _stream()),
           "vitmi_patch_wide_weight")
-    _fold_cache[key] = (stamp, [weakref.ref(t) for t in parts], (w_wide, b_wide))
     return w_wide, b_wide
 
 
