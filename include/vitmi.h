@@ -369,7 +369,8 @@ int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const voi
 /* At the small geometry (bf16, D <= 256 and a multiple of 32, hidden width a multiple of 32, 16-byte aligned
  * operands) the block calls run as one-launch kernels that keep the sub-block's activations in LDS; same outputs to the
  * bf16 bar.  vitmi_debug_set_small_fused(mask): bit 0 = the MLP sub-block's forward, bit 1 = the attention
- * sub-block's forward (up to 96 tokens, heads of 8 or 16, no probability export; default both);
+ * sub-block's forward (up to 96 tokens, heads of 8 or 16, no probability export), bit 2 = the MLP sub-block's backward
+ * (default 3: the two forward kernels; a negative mask restores the default);
  * process-wide, for benchmarking and for the tests that compare the two forms. */
 int vitmi_debug_set_small_fused(int mask);
 /* The two weight-gradient products of a sub-block's backward call may run on a second stream of the library's own,

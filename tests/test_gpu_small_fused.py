@@ -78,7 +78,7 @@ def _cifar_step(overlap, fused, seed=3):
     x = torch.randn(16, 3, 32, 32, generator=g).to(DEV)
     y = torch.randint(0, 10, (16,), generator=g).to(DEV)
     check(lib.vitmi_debug_set_wgrad_overlap(overlap))
-    check(lib.vitmi_debug_set_small_fused(-1 if fused else 0))
+    check(lib.vitmi_debug_set_small_fused(int(fused) if fused is not True else -1))
     try:
         logits = m(x)
         torch.nn.functional.cross_entropy(logits, y).backward()
@@ -100,9 +100,10 @@ def test_weight_gradients_on_the_second_stream_change_nothing():
             assert torch.equal(grads[k], ref[k]), (mode, k)
 
 
-def test_model_step_with_and_without_the_one_launch_kernels():
-    ref_logits, ref = _cifar_step(-1, False)
-    logits, grads = _cifar_step(-1, True)
+@pytest.mark.parametrize("mask", [3, 7])
+def test_model_step_with_and_without_the_one_launch_kernels(mask):
+    ref_logits, ref = _cifar_step(-1, 0)
+    logits, grads = _cifar_step(-1, mask)
     assert rel_err(logits, ref_logits) < 2e-2
     for k in ref:
         assert rel_err(grads[k], ref[k]) < 2e-2, k
@@ -159,3 +160,52 @@ def test_attention_block_forward_one_launch_against_steps_and_fp64(B, N, D, H, D
     assert rel_err(fused["o"].double(), o) < 2e-2
     assert rel_err(fused["lse"].double(), torch.logsumexp(dots, -1)) < 2e-2
     assert rel_err(fused["y"].double(), y) < 2e-2
+
+
+def _ff_block_bwd(rows, D, M, fused, erf, seed=0):
+    from visiontransformer_amd._lib import check, lib
+    from visiontransformer_amd.ops import _p, _stream
+    ins, fwd = _ff_block(rows, D, M, False, erf, seed)          # the saved tensors of the launch-per-step forward
+    g = torch.Generator().manual_seed(seed + 100)
+    dy = (torch.randn(rows, D, generator=g) * 0.1).to(DEV, BF)
+    w1_t, w2_t = ins["w1"].t().contiguous(), ins["w2"].t().contiguous()
+    out = dict(dx=torch.empty(rows, D, dtype=BF, device=DEV), dgamma=torch.empty(D, device=DEV),
+               dbeta=torch.empty(D, device=DEV), dw1=torch.empty(M, D, device=DEV), db1=torch.empty(M, device=DEV),
+               dw2=torch.empty(D, M, device=DEV), db2=torch.empty(D, device=DEV))
+    ws = torch.empty(int(lib.vitmi_ff_block_bwd_workspace_bytes(1, rows, D, M)) + 256, dtype=torch.uint8, device=DEV)
+    check(lib.vitmi_debug_set_small_fused(7 if fused else 0))      # bit 2: the backward kernel is opt-in
+    check(lib.vitmi_set_gelu_mode(1 if erf else 0))
+    try:
+        check(lib.vitmi_ff_block_bwd(1, rows, D, M, _p(dy), _p(ins["x"]), _p(fwd["xn"]), _p(fwd["u"]), _p(fwd["h"]),
+                                     _p(ins["gamma"]), _p(fwd["mean"]), _p(fwd["rstd"]), _p(ins["w1"]), _p(w1_t),
+                                     _p(ins["w2"]), _p(w2_t), _p(out["dx"]), _p(out["dgamma"]), _p(out["dbeta"]),
+                                     _p(out["dw1"]), _p(out["db1"]), _p(out["dw2"]), _p(out["db2"]), _p(ws), _stream()),
+              "vitmi_ff_block_bwd")
+        torch.cuda.synchronize()
+    finally:
+        check(lib.vitmi_debug_set_small_fused(-1))
+        check(lib.vitmi_set_gelu_mode(0))
+    return ins, fwd, dy, out
+
+
+@pytest.mark.parametrize("erf", [False, True])
+@pytest.mark.parametrize("rows,D,M", [(256 * 65, 192, 512), (64 * 65, 192, 512), (37, 64, 128), (1000, 256, 1024),
+                                      (16 * 5 * 3 + 1, 128, 96), (96, 96, 32)])
+def test_ff_block_backward_one_launch_against_steps_and_fp64(rows, D, M, erf):
+    ins, fwd, dy, fused = _ff_block_bwd(rows, D, M, True, erf)
+    _, _, _, steps = _ff_block_bwd(rows, D, M, False, erf)
+    # against the launch-per-step form: dxn stays fp32 here instead of being rounded to bf16 on its way to the
+    # LayerNorm backward, so the two differ by that rounding
+    for k in ("dx", "dgamma", "dbeta", "dw1", "db1", "dw2", "db2"):
+        assert rel_err(fused[k].float(), steps[k].float()) < 1e-2, k
+    # fp64 evaluation through autograd from the same bf16 operands
+    x = ins["x"].double().requires_grad_(True)
+    gamma, beta = ins["gamma"].double().requires_grad_(True), ins["beta"].double().requires_grad_(True)
+    w1, b1 = ins["w1"].double().requires_grad_(True), ins["b1"].double().requires_grad_(True)
+    w2, b2 = ins["w2"].double().requires_grad_(True), ins["b2"].double().requires_grad_(True)
+    xn = torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5)
+    y = torch.nn.functional.gelu(xn @ w1.t() + b1) @ w2.t() + b2 + x
+    y.backward(dy.double())
+    ref = dict(dx=x.grad, dgamma=gamma.grad, dbeta=beta.grad, dw1=w1.grad, db1=b1.grad, dw2=w2.grad, db2=b2.grad)
+    for k, v in ref.items():
+        assert rel_err(fused[k].double(), v) < 2e-2, k

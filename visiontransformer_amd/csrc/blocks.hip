@@ -110,6 +110,13 @@ extern "C" int vitmi_debug_set_wgrad_overlap(int mode) {
 // the sub-block as ONE launch at the small geometry (small.hip); NOT_TAKEN = operands not 16-byte aligned, nothing enqueued
 enum { VITMI_SMALL_NOT_TAKEN = 1000 };
 bool vitmi_ff_small_ok(int dt, long long rows, int D, int M);
+bool vitmi_ff_small_bwd_ok(int dt, long long rows, int D, int M);
+long long vitmi_ff_small_bwd_partial_bytes(long long rows, int D, int M);
+int vitmi_ff_small_bwd(long long rows, int D, int M, const void* dy, const void* x, const void* u, const float* gamma,
+                       const float* mean, const float* rstd, const void* w2_t, const void* w1_t, void* du, void* dx,
+                       float* partial, int erf_pair, void* stream);
+int vitmi_ff_small_bwd_final(long long rows, int D, int M, const float* partial, float* db1, float* dgamma, float* dbeta,
+                             float* db2, void* stream);
 int vitmi_ff_small_fwd(long long rows, int D, int M, const void* x, const float* gamma, const float* beta, float eps,
                        const void* w1, const float* b1, const void* w2, const float* b2, void* xn, float* mean, float* rstd,
                        void* u, void* h, void* y, int erf_pair, void* stream);
@@ -143,7 +150,8 @@ extern "C" int vitmi_ff_block_fwd(int dt, int rows, int D, int M, const void* x,
 // scratch of the launches on the caller's stream; the weight-gradient pair has its own region behind it (it may run
 // beside them)
 static long long ff_chain_scratch(long long rows, int D, int M) {
-    return align256(max2(vitmi_gemm_colsum_workspace_bytes(rows, M), vitmi_layernorm_bwd_workspace_bytes(rows, D)));
+    return align256(max2(max2(vitmi_gemm_colsum_workspace_bytes(rows, M), vitmi_layernorm_bwd_workspace_bytes(rows, D)),
+                         vitmi_ff_small_bwd_partial_bytes(rows, D, M)));
 }
 
 extern "C" long long vitmi_ff_block_bwd_workspace_bytes(int dt, int rows, int D, int M) {
@@ -170,6 +178,25 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
     if (sd) {
         STEP(side_fork(sd, stream));
         STEP(vitmi_gemm_wgrad(dt, D, M, rows, dy, D, h, M, dw2, M, wg_scratch, sd->s));
+    }
+    if (w1_t && w2_t && vitmi_ff_small_bwd_ok(dt, rows, D, M)) {
+        // one launch for du, dxn and the LayerNorm backward (small.hip); the sums for db1, dgamma, dbeta, db2 are
+        // finished by a small kernel that, like the weight gradients, need not sit on the caller's chain
+        const int rc = vitmi_ff_small_bwd(rows, D, M, dy, x, u, gamma, mean, rstd, w2_t, w1_t, du, dx, (float*)scratch,
+                                          g_classic_gelu_pair, stream);
+        if (rc != VITMI_SMALL_NOT_TAKEN) {
+            if (rc != VITMI_OK) return rc;
+            if (sd) {
+                STEP(side_fork(sd, stream, true));
+                STEP(vitmi_gemm_wgrad(dt, M, D, rows, du, M, xn, D, dw1, D, wg_scratch, sd->s));
+                STEP(vitmi_ff_small_bwd_final(rows, D, M, (const float*)scratch, db1, dgamma, dbeta, db2, sd->s));
+                STEP(side_join(sd, stream));
+            } else {
+                STEP(vitmi_gemm_wgrad_pair(dt, rows, D, M, dy, D, h, M, dw2, M, D, du, M, xn, D, dw1, wg_scratch, stream));
+                STEP(vitmi_ff_small_bwd_final(rows, D, M, (const float*)scratch, db1, dgamma, dbeta, db2, stream));
+            }
+            return VITMI_OK;
+        }
     }
     STEP(input_grad(dt, rows, M, D, dy, w2, w2_t, du, g_classic_gelu_pair ? VITMI_EPI_DGELU : VITMI_EPI_MULAUX,
                     const_cast<void*>(u), db1, scratch, stream));

@@ -123,6 +123,213 @@ __global__ __launch_bounds__(SM_THREADS) void ff_small_fwd_kernel(FfSmallArgs a)
     }
 }
 
+// ---- backward of the same sub-block (mymodel/ViT.py:52-58, 62-73, 120) for a strip of 16 MT rows ----------------------
+//   du  = (dy W2) * gelu'(pre-activation)        -> written out (operand of dW1 = du^T LN(x)) and kept in LDS
+//   dxn = du W1                                  -> stays in registers (fp32)
+//   dx  = LayerNorm backward of dxn at x, + dy   (the residual branch)
+// and the strip's column sums for db1 (of du), dgamma, dbeta (of dxn) and db2 (of dy) as one row of `partial`
+// ([strips][M + 3 D]); ff_small_bwd_final_kernel adds the rows in strip order.  W2 and W1 are read through their
+// transposed copies ([M][D] and [D][M]: the output feature of each product indexes a row).
+struct FfSmallBwdArgs {
+    const bf16_t *dy, *x, *u;
+    const float *gamma, *mean, *rstd;
+    const bf16_t *w2_t, *w1_t;
+    bf16_t *du, *dx;
+    float* partial;
+    long long rows;
+    int D, M;
+    int erf_pair;  // what u holds: 1 = the pre-activation, 0 = GELU'(pre-activation) as IEEE half
+};
+
+template <int MT>
+__global__ __launch_bounds__(SM_THREADS) void ff_small_bwd_kernel(FfSmallBwdArgs a) {
+    constexpr int R = MT * 16;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int D = a.D, M = a.M, ldx = D + SM_PAD, ldh = M + SM_PAD;
+    bf16_t* dys = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* dus = dys + R * ldx;
+    float* red = reinterpret_cast<float*>(dus + R * ldh);  // [2][SM_WAVES][R] row sums of the LayerNorm backward
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row0 = (long long)blockIdx.x * R;
+    const int nrows = (int)(a.rows - row0 < R ? a.rows - row0 : R);
+    const int tok = lane & 15, f8 = (lane >> 4) * 8;
+    float* part = a.partial + (long long)blockIdx.x * (M + 3 * D);
+    // the strip of dy into LDS (zeros past the end of the matrix)
+    for (int i = threadIdx.x; i < R * (D / 8); i += SM_THREADS) {
+        const int r = i / (D / 8), c = (i - r * (D / 8)) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (r < nrows) v = *reinterpret_cast<const u32x4*>(a.dy + (row0 + r) * D + c);
+        *reinterpret_cast<u32x4*>(dys + r * ldx + c) = v;
+    }
+    __syncthreads();
+    for (int p = wave; p < M / 32; p += SM_WAVES) {
+        const int n = p * 32 + f8;
+        bf16x8 uq[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok < nrows ? m * 16 + tok : 0;
+            uq[m] = *reinterpret_cast<const bf16x8*>(a.u + (row0 + r) * M + n);
+        }
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rows_gemm<MT, 2, 3>(a.w2_t, D, p * 32, D / 32, dys, ldx, lane, acc);
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        bf16x8 dq[MT];
+        if (a.erf_pair) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) dq[m][t] = (bf16_t)(acc[t >> 2][m][t & 3] * gelu_grad_fast((float)uq[m][t]));
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) dq[m][t] = (bf16_t)(acc[t >> 2][m][t & 3] * deriv_unpack(uq[m][t]));
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) cs[t] += (float)dq[m][t];  // rows past the end: dy = 0, so 0
+            *reinterpret_cast<bf16x8*>(dus + r * ldh + n) = dq[m];
+            if (r < nrows) *reinterpret_cast<bf16x8*>(a.du + (row0 + r) * M + n) = dq[m];
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) cs[t] += __shfl_xor(cs[t], o, 64);
+        if (tok == 0) {
+            *reinterpret_cast<f32x4*>(part + n) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+            *reinterpret_cast<f32x4*>(part + n + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+        }
+    }
+    __syncthreads();
+    // dxn: one 32-feature pass per wave (D <= 256), then the LayerNorm backward across the waves
+    const bool active = wave < D / 32;
+    const int n = wave * 32 + f8;
+    f32x4 acc[2][MT];
+    bf16x8 xq[MT];
+    float mu[MT], rs[MT];
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok < nrows ? m * 16 + tok : 0;
+            xq[m] = *reinterpret_cast<const bf16x8*>(a.x + (row0 + r) * D + n);
+            mu[m] = a.mean[row0 + r];
+            rs[m] = a.rstd[row0 + r];
+        }
+        g0 = *reinterpret_cast<const f32x4*>(a.gamma + n);
+        g1 = *reinterpret_cast<const f32x4*>(a.gamma + n + 4);
+        rows_gemm<MT, 2, 4>(a.w1_t, M, wave * 32, M / 32, dus, ldh, lane, acc);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float xh = ((float)xq[m][t] - mu[m]) * rs[m];
+                const float g = acc[t >> 2][m][t & 3] * (t < 4 ? g0[t & 3] : g1[t & 3]);
+                s1 += g;
+                s2 += g * xh;
+            }
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 16) {
+                red[wave * R + m * 16 + tok] = s1;
+                red[(SM_WAVES + wave) * R + m * 16 + tok] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+        float dg[8], db[8], dr[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) dg[t] = db[t] = dr[t] = 0.f;
+        const int nw = D / 32;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok;
+            float c1 = 0.f, c2 = 0.f;
+            for (int w = 0; w < nw; ++w) {
+                c1 += red[w * R + r];
+                c2 += red[(SM_WAVES + w) * R + r];
+            }
+            c1 /= (float)D;
+            c2 /= (float)D;
+            const bf16x8 dyv = *reinterpret_cast<const bf16x8*>(dys + r * ldx + n);
+            bf16x8 o;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float xh = ((float)xq[m][t] - mu[m]) * rs[m];
+                const float dxn = acc[t >> 2][m][t & 3];
+                const float g = dxn * (t < 4 ? g0[t & 3] : g1[t & 3]);
+                const float res = (float)dyv[t];
+                o[t] = (bf16_t)(rs[m] * (g - c1 - xh * c2) + res);
+                dg[t] += dxn * xh;  // rows past the end: du = 0, so dxn = 0
+                db[t] += dxn;
+                dr[t] += res;
+            }
+            if (r < nrows) *reinterpret_cast<bf16x8*>(a.dx + (row0 + r) * D + n) = o;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                dg[t] += __shfl_xor(dg[t], o, 64);
+                db[t] += __shfl_xor(db[t], o, 64);
+                dr[t] += __shfl_xor(dr[t], o, 64);
+            }
+        if (tok == 0) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                part[M + n + t] = dg[t];
+                part[M + D + n + t] = db[t];
+                part[M + 2 * D + n + t] = dr[t];
+            }
+        }
+    }
+}
+
+// out[c] = sum over the strips' rows of partial[strip][c], in strip order; c runs over [db1 (M) | dgamma | dbeta | db2 (D each)]
+__global__ __launch_bounds__(256) void ff_small_bwd_final_kernel(const float* __restrict__ partial, int strips, int M, int D,
+                                                                 float* __restrict__ db1, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, float* __restrict__ db2) {
+    const int cols = M + 3 * D;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < cols) {
+        int k = grp;
+        for (; k + 4 < strips; k += 8) {
+            a0 += partial[(long long)k * cols + c];
+            a1 += partial[(long long)(k + 4) * cols + c];
+        }
+        if (k < strips) a0 += partial[(long long)k * cols + c];
+    }
+    __shared__ float red[4][64];
+    red[grp][threadIdx.x & 63] = a0 + a1;
+    __syncthreads();
+    if (grp == 0 && c < cols) {
+        const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        if (c < M)
+            db1[c] = s;
+        else if (c < M + D)
+            dgamma[c - M] = s;
+        else if (c < M + 2 * D)
+            dbeta[c - M - D] = s;
+        else
+            db2[c - M - 2 * D] = s;
+    }
+}
+
 // token tiles per workgroup: the fewest grid rounds over the CUs, then the smaller strip
 int pick_strip_tiles(long long rows, int cus, size_t lds_per_tile) {
     int best = 2;
@@ -166,8 +373,44 @@ int launch_ff_small(const FfSmallArgs& a, hipStream_t s) {
     return VITMI_OK;
 }
 
+// (the backward kernel is opt-in: beside the weight gradients on the second stream it is no faster than the four
+// launches it replaces -- 3.29 -> 3.46 ms per step at the 32-pixel geometry, batch 256, graph replay; it saves host time
+// when the step is issued eagerly: 4.57 -> 4.45 ms)
 constexpr int SMALL_DEFAULT = 3;
-int g_small_fused = SMALL_DEFAULT;  // bit 0: MLP sub-block forward, bit 1: attention sub-block forward
+template <int MT>
+int launch_ff_small_bwd(const FfSmallBwdArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)MT * 16 * ((a.D + SM_PAD) + (a.M + SM_PAD)) * sizeof(bf16_t) + (size_t)2 * SM_WAVES * MT * 16 * sizeof(float);
+    static size_t granted = 0;
+    if (lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_small_bwd_kernel<MT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return vitmi_hip_fail(e, "ff_small_bwd: hipFuncSetAttribute");
+        granted = lds;
+    }
+    const int grid = (int)((a.rows + MT * 16 - 1) / (MT * 16));
+    hipLaunchKernelGGL(ff_small_bwd_kernel<MT>, dim3(grid), dim3(SM_THREADS), lds, s, a);
+    VITMI_LAUNCH_CHECK("ff_small_bwd_kernel");
+    return VITMI_OK;
+}
+
+// the strip height of the backward kernel: a function of the shape alone (the partial-sum buffer is sized from it)
+int ff_small_bwd_tiles(long long rows, int D, int M) {
+    int best = 2;
+    long long best_cost = -1;
+    for (int mt = 2; mt <= 6; ++mt) {
+        const size_t lds = (size_t)mt * 16 * ((D + SM_PAD) + (M + SM_PAD)) * sizeof(bf16_t) + (size_t)2 * SM_WAVES * mt * 16 * sizeof(float);
+        if (lds > 160 * 1024) break;
+        const long long wgs = (rows + mt * 16 - 1) / (mt * 16);
+        const long long cost = ((wgs + 255) / 256) * (mt + 2);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = mt;
+        }
+    }
+    return best;
+}
+
+int g_small_fused = SMALL_DEFAULT;  // bit 0: MLP sub-block forward, bit 1: attention sub-block forward, bit 2: MLP sub-block backward
 
 }  // namespace
 
@@ -208,4 +451,45 @@ int vitmi_ff_small_fwd(long long rows, int D, int M, const void* x, const float*
         case 5: return launch_ff_small<5>(a, s);
         default: return launch_ff_small<6>(a, s);
     }
+}
+
+// ---- MLP sub-block backward
+bool vitmi_ff_small_bwd_ok(int dt, long long rows, int D, int M) {
+    if (!(g_small_fused & 4) || dt != VITMI_BF16 || rows <= 0) return false;
+    if (D < 32 || D > 256 || D % 32 != 0 || M < 32 || M % 32 != 0) return false;
+    return (size_t)2 * 16 * ((D + SM_PAD) + (M + SM_PAD)) * sizeof(bf16_t) + (size_t)2 * SM_WAVES * 32 * sizeof(float) <= 160 * 1024;
+}
+// bytes of the per-strip partial sums the backward kernel leaves for its final reduction
+long long vitmi_ff_small_bwd_partial_bytes(long long rows, int D, int M) {
+    if (rows <= 0 || D <= 0 || M <= 0) return 0;
+    const int mt = ff_small_bwd_tiles(rows, D, M);
+    return ((rows + mt * 16 - 1) / (mt * 16)) * (long long)(M + 3 * D) * (long long)sizeof(float);
+}
+// the fused kernel on `stream`; the final reduction of the bias / LayerNorm-parameter gradients on `final_stream`
+// (which must already be ordered behind `stream`'s kernel when it differs).  VITMI_SMALL_NOT_TAKEN: nothing enqueued.
+int vitmi_ff_small_bwd(long long rows, int D, int M, const void* dy, const void* x, const void* u, const float* gamma,
+                       const float* mean, const float* rstd, const void* w2_t, const void* w1_t, void* du, void* dx,
+                       float* partial, int erf_pair, void* stream) {
+    if (!(aligned16(dy) && aligned16(x) && aligned16(u) && aligned16(gamma) && aligned16(w2_t) && aligned16(w1_t) && aligned16(du) &&
+          aligned16(dx) && aligned16(partial)))
+        return VITMI_SMALL_NOT_TAKEN;
+    FfSmallBwdArgs a{(const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)u, gamma, mean, rstd, (const bf16_t*)w2_t,
+                     (const bf16_t*)w1_t, (bf16_t*)du, (bf16_t*)dx, partial, rows, D, M, erf_pair};
+    hipStream_t s = as_stream(stream);
+    switch (ff_small_bwd_tiles(rows, D, M)) {
+        case 2: return launch_ff_small_bwd<2>(a, s);
+        case 3: return launch_ff_small_bwd<3>(a, s);
+        case 4: return launch_ff_small_bwd<4>(a, s);
+        case 5: return launch_ff_small_bwd<5>(a, s);
+        default: return launch_ff_small_bwd<6>(a, s);
+    }
+}
+int vitmi_ff_small_bwd_final(long long rows, int D, int M, const float* partial, float* db1, float* dgamma, float* dbeta,
+                             float* db2, void* stream) {
+    const int mt = ff_small_bwd_tiles(rows, D, M);
+    const int strips = (int)((rows + mt * 16 - 1) / (mt * 16));
+    hipLaunchKernelGGL(ff_small_bwd_final_kernel, dim3((M + 3 * D + 63) / 64), dim3(256), 0, as_stream(stream), partial, strips, M,
+                       D, db1, dgamma, dbeta, db2);
+    VITMI_LAUNCH_CHECK("ff_small_bwd_final_kernel");
+    return VITMI_OK;
 }
