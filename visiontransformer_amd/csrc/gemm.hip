@@ -297,34 +297,36 @@ struct F32Operand {
 // Both tiles sit in LDS as [row][k] with rows 17 floats apart.
 // blockIdx.z walks K in chunks of k_chunk (weight gradients: K = tokens, few output tiles): slab z of the partial
 // products goes to C + z * slab_stride and f32_slab_sum_kernel adds the slabs in index order.
-template <int EPI>
+template <int EPI, int T = 64>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand B, Epilogue epi, int M, int N, int K,
                                                        int k_chunk, long long slab_stride) {
-    constexpr int TM = 64, TN = 64, TK = 16, LD = TK + 1;
-    __shared__ float As[TM][LD];
-    __shared__ float Bs[TN][LD];
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    // T x T output tile: 64 (each wave a 32 x 32 quarter, 2 x 2 MFMA tiles) or, for products of few tiles (the
+    // classifier head: 256 x 100 outputs), 32 (each wave one 16 x 16 tile: four times the blocks)
+    constexpr int TK = 16, LD = TK + 1, PER = T * TK / 256, SUB = T / 32;
+    __shared__ float As[T][LD];
+    __shared__ float Bs[T][LD];
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
     const int kz0 = blockIdx.z * k_chunk, kz1 = min(K, kz0 + k_chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    const int wm = (wave >> 1) * (T / 2), wn = (wave & 1) * (T / 2);
     const int fr = lane & 15, fk = lane >> 4;
     const bool a_kc = A.patch ? (A.token_rows != 0) : (A.s_k == 1);
     const bool b_kc = B.patch ? (B.token_rows != 0) : (B.s_k == 1);
-    f32x4 acc[2][2];
+    f32x4 acc[SUB][SUB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < SUB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < SUB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // the next tile's elements are requested before the current tile's products are issued
-    float av[4], bv[4];
+    float av[PER], bv[PER];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PER; ++i) {
             const int c = threadIdx.x + i * 256;
             int r, k;
-            if (a_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
+            if (a_kc) { k = c & 15; r = c >> 4; } else { r = c % T; k = c / T; }
             av[i] = A.at(m0 + r, k0 + k, kz1);
-            if (b_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
+            if (b_kc) { k = c & 15; r = c >> 4; } else { r = c % T; k = c / T; }
             bv[i] = B.at(n0 + r, k0 + k, kz1);
         }
     };
@@ -332,35 +334,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand 
     for (int k0 = kz0; k0 < kz1; k0 += TK) {
         __syncthreads();  // the previous tile's fragments have been read
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PER; ++i) {
             const int c = threadIdx.x + i * 256;
             int r, k;
-            if (a_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
+            if (a_kc) { k = c & 15; r = c >> 4; } else { r = c % T; k = c / T; }
             As[r][k] = av[i];
-            if (b_kc) { k = c & 15; r = c >> 4; } else { r = c & 63; k = c >> 6; }
+            if (b_kc) { k = c & 15; r = c >> 4; } else { r = c % T; k = c / T; }
             Bs[r][k] = bv[i];
         }
         __syncthreads();
         if (k0 + TK < kz1) fetch(k0 + TK);
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 4) {
-            const float a0 = As[wm + fr][kk + fk], a1 = As[wm + 16 + fr][kk + fk];
-            const float b0 = Bs[wn + fr][kk + fk], b1 = Bs[wn + 16 + fr][kk + fk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+            float a[SUB], b[SUB];
+#pragma unroll
+            for (int i = 0; i < SUB; ++i) {
+                a[i] = As[wm + 16 * i + fr][kk + fk];
+                b[i] = Bs[wn + 16 * i + fr][kk + fk];
+            }
+#pragma unroll
+            for (int i = 0; i < SUB; ++i)
+#pragma unroll
+                for (int j = 0; j < SUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
     if (slab_stride > 0) epi.C = reinterpret_cast<float*>(epi.C) + (long long)blockIdx.z * slab_stride;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < SUB; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + wm + i * 16 + 4 * fk + r;
             if (m >= M) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < SUB; ++j) {
                 const int n = n0 + wn + j * 16 + fr;
                 if (n < N) epilogue_store<EPI, float, float>(epi, m, n, acc[i][j][r]);
             }
@@ -400,7 +406,11 @@ inline int launch_f32_plain(const F32Operand& a, const F32Operand& b, Epilogue e
     }
     dim3 grid(ceil_div(N, 64), ceil_div(M, 64), splits);
     if (splits <= 1) {
-        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
+        if ((long long)grid.x * grid.y < 128)
+            hipLaunchKernelGGL((gemm_f32_kernel<VITMI_EPI_NONE, 32>), dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, s, a, b,
+                               epi, M, N, K, K, 0ll);
+        else
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
         VITMI_LAUNCH_CHECK(what);
         return VITMI_OK;
     }
@@ -484,7 +494,7 @@ static int gemm_impl(int dt, int M, int N, int K, const void* A, long long sam, 
         F32Operand b{(const float*)B, sbn, sbk, N, 0, 0, 0, 0, 0, 0, 0, 0};
         dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
         if (epilogue == VITMI_EPI_NONE)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
+            return launch_f32_plain(a, b, epi, M, N, K, nullptr, s, "vitmi_gemm(f32)");
         else if (epilogue == VITMI_EPI_GELU)
             hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
         else if (epilogue == VITMI_EPI_GELU_D)
