@@ -40,7 +40,22 @@ for res in (0, 8, 64, 128):
     lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.BF16, 50432, 32768, 32768, 32768, 32768)
 assert lib.vitmi_set_reserved_cus(0) == 0
 assert lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.BF16, 50400, 768, 768, 2304, 768) >= 0
-assert lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.F32, 50432, 768, 768, 2304, 768) == 0
+# fp32 weight gradients split the token axis into slabs (few output tiles, K = tokens): a workspace of their own
+assert lib.vitmi_gemm_wgrad_pair_workspace_bytes(_lib.F32, 50432, 768, 768, 2304, 768) > 0
+assert lib.vitmi_gemm_wgrad_workspace_bytes(_lib.F32, 192, 512, 4160) > 0
+assert lib.vitmi_gemm_wgrad_workspace_bytes(_lib.F32, 3072, 768, 100) == 0
+lib.vitmi_gemm_wgrad_workspace_bytes(_lib.F32, 4096, 4096, big)
+# the 32-pixel geometry: block workspaces with the one-launch kernels' partial sums, patches narrower than 8 pixels
+for dt in (_lib.F32, _lib.BF16):
+    assert lib.vitmi_ff_block_bwd_workspace_bytes(dt, 16640, 192, 512) > 0
+    assert lib.vitmi_attn_block_bwd_workspace_bytes(dt, 256, 65, 192, 12, 8) > 0
+assert lib.vitmi_patch_wide_group(_lib.BF16, _lib.BF16, 256, 3, 32, 32, 4, 192) == 2
+assert lib.vitmi_patch_wide_group(_lib.BF16, _lib.BF16, 256, 3, 20, 20, 4, 192) == 0
+assert lib.vitmi_patch_wide_group(_lib.F32, _lib.F32, 256, 3, 32, 32, 4, 192) == 0
+assert lib.vitmi_patch_embed_bwd_w_wide_workspace_bytes(256, 3, 32, 32, 4, 192) > 0
+lib.vitmi_patch_embed_bwd_w_wide_workspace_bytes(4096, 3, 224, 224, 4, 768)
+assert lib.vitmi_patch_embed_fwd_wide(None, None, None, None, 1, 3, 32, 32, 4, 192, 0, None) != 0
+assert lib.vitmi_patch_wide_weight(None, None, None, None, 192, 3, 4, None) != 0
 assert lib.vitmi_gemm_wgrad_pair(_lib.BF16, 64, 256, 256, None, 256, None, 256, None, 256, 256, None, 256, None, 256, None,
                                  None, None) != 0
 assert lib.vitmi_attn_block_infer_workspace_bytes(256, 197, 768, 12, 64) > 0
@@ -60,7 +75,8 @@ assert lib.vitmi_attn_bwd(None, None, None, None, None, None, None, _lib.BF16, 1
 assert lib.vitmi_set_reserved_cus(7) != 0 and b"multiple of 8" in lib.vitmi_last_error()
 assert lib.vitmi_set_reserved_cus(0) == 0
 for knob in ("vitmi_debug_set_nt_group", "vitmi_debug_set_nt_tail_split", "vitmi_debug_set_gelu_pair",
-             "vitmi_debug_set_attn_head_groups", "vitmi_debug_set_tn_batch"):
+             "vitmi_debug_set_attn_head_groups", "vitmi_debug_set_tn_batch", "vitmi_debug_set_small_fused",
+             "vitmi_debug_set_wgrad_overlap", "vitmi_debug_set_qkv_planes", "vitmi_debug_set_ghost_norms"):
     getattr(lib, knob)(1)
 print("host-sanitized checks ok")
 """
