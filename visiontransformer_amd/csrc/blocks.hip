@@ -39,6 +39,7 @@ int input_grad(int dt, int T, int K, int N, const void* dy, const void* w, const
 // produces its dY operand -- and joined back before the call returns, so that they run beside the input-gradient
 // chain and the LayerNorm backward.  The caller's stream sees
 // one call as before (also under stream capture: the fork and join become graph edges).
+// (one per host thread and device, created on first use and kept for the life of the process)
 struct Side {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, fork2 = nullptr, join = nullptr;
@@ -59,7 +60,7 @@ Side* side_stream() {
             hipEventCreateWithFlags(&sd.fork2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
-            sd.failed = true;  // e.g. first use inside a stream capture: stay on the caller's stream
+            sd.failed = true;  // stay on the caller's stream from now on (this thread, this device)
             sd.s = nullptr;
             return nullptr;
         }
@@ -74,16 +75,17 @@ Side* side_stream() {
 // step with the forks, graph 3.9 -> 3.3 ms).
 Side* overlap_side(long long rows, int D, void* stream) {
     if (g_overlap == 0) return nullptr;
-    if (g_overlap < 0) {
-        if (rows * (long long)D > (8ll << 20)) return nullptr;
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(as_stream(stream), &st) != hipSuccess) {
-            (void)hipGetLastError();
-            return nullptr;
-        }
-        if (st != hipStreamCaptureStatusActive) return nullptr;
+    if (g_overlap > 0) return side_stream();
+    if (rows * (long long)D > (8ll << 20)) return nullptr;
+    // created at the first small-shape call, which is normally an eager one: no stream creation inside a capture
+    Side* sd = side_stream();
+    if (!sd) return nullptr;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(as_stream(stream), &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
     }
-    return side_stream();
+    return st == hipStreamCaptureStatusActive ? sd : nullptr;
 }
 
 // the second stream waits for everything enqueued on the caller's stream so far

@@ -357,16 +357,25 @@ int device_cus() {
     return cus;
 }
 
+// Raise a kernel's dynamic-LDS limit to the whole 160 KB once per device (bit d of *done_mask = done on device d).
+int allow_full_lds(const void* fn, unsigned long long* done_mask, const char* who) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return vitmi_hip_fail(e, who);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return VITMI_OK;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return vitmi_hip_fail(e, who);
+    __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
+    return VITMI_OK;
+}
+
 template <int MT>
 int launch_ff_small(const FfSmallArgs& a, hipStream_t s) {
     const size_t lds = (size_t)MT * 16 * ((a.D + SM_PAD) + (a.M + SM_PAD)) * sizeof(bf16_t);
-    static size_t granted = 0;
-    if (lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_small_fwd_kernel<MT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return vitmi_hip_fail(e, "ff_small_fwd: hipFuncSetAttribute");
-        granted = lds;
-    }
+    static unsigned long long done = 0;
+    const int rc = allow_full_lds(reinterpret_cast<const void*>(&ff_small_fwd_kernel<MT>), &done, "ff_small_fwd: LDS attribute");
+    if (rc != VITMI_OK) return rc;
     const int grid = (int)((a.rows + MT * 16 - 1) / (MT * 16));
     hipLaunchKernelGGL(ff_small_fwd_kernel<MT>, dim3(grid), dim3(SM_THREADS), lds, s, a);
     VITMI_LAUNCH_CHECK("ff_small_fwd_kernel");
@@ -380,13 +389,9 @@ constexpr int SMALL_DEFAULT = 3;
 template <int MT>
 int launch_ff_small_bwd(const FfSmallBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)MT * 16 * ((a.D + SM_PAD) + (a.M + SM_PAD)) * sizeof(bf16_t) + (size_t)2 * SM_WAVES * MT * 16 * sizeof(float);
-    static size_t granted = 0;
-    if (lds > granted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ff_small_bwd_kernel<MT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return vitmi_hip_fail(e, "ff_small_bwd: hipFuncSetAttribute");
-        granted = lds;
-    }
+    static unsigned long long done = 0;
+    const int rc = allow_full_lds(reinterpret_cast<const void*>(&ff_small_bwd_kernel<MT>), &done, "ff_small_bwd: LDS attribute");
+    if (rc != VITMI_OK) return rc;
     const int grid = (int)((a.rows + MT * 16 - 1) / (MT * 16));
     hipLaunchKernelGGL(ff_small_bwd_kernel<MT>, dim3(grid), dim3(SM_THREADS), lds, s, a);
     VITMI_LAUNCH_CHECK("ff_small_bwd_kernel");
