@@ -502,6 +502,26 @@ int vitmi_adam_step_multi(const vitmi_adam_tensor* tensors, int n_tensors, const
                           int n_chunks, int chunk_elems, float lr, float beta1, float beta2, float eps,
                           float weight_decay, int step, float grad_scale, void* stream);
 
+/* vitmi_adam_step_multi for weight matrices that keep a transposed bf16 copy (the B operand of the input-gradient
+ * products, x.grad = dy @ W of every nn.Linear, mymodel/ViT.py:65-68,86,88): one block per 64 x 64 tile updates the
+ * tile, writes the row-major bf16 copy (param_bf16, may be NULL) and the transposed one (param_bf16_t[c][r], required)
+ * in the same pass.  mats and tile_start live on the device; tile_start[j] = number of 64 x 64 tiles of the matrices
+ * before j (ceil(rows/64) * ceil(cols/64) each), total_tiles their sum = the grid.  Contract: cols % 4 == 0, the four
+ * fp32 pointers 16-byte aligned, param_bf16 and param_bf16_t 8-byte aligned. */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    void* param_bf16;   /* [rows][cols], may be NULL */
+    void* param_bf16_t; /* [cols][rows] */
+    long long rows;
+    long long cols;
+} vitmi_adam_matrix;
+int vitmi_adam_step_matrices(const vitmi_adam_matrix* mats, const long long* tile_start, int n_mats,
+                             long long total_tiles, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int step, float grad_scale, void* stream);
+
 /* vitmi_transpose_cast (fp32 source) for many matrices in ONE launch: job j writes dst[c][r] = (bf16) src[r][c]
  * for its rows x cols matrix.  jobs and tile_start live on the device; tile_start[j] = number of 64 x 64 tiles
  * of the jobs before j (ceil(rows/64) * ceil(cols/64) each), total_tiles their sum = the grid.  Used after the

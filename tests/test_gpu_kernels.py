@@ -519,28 +519,46 @@ def test_upload_ring_reuses_its_slots_safely():
     assert np.array_equal(ops.upload(big, DEV).cpu().numpy(), big)
 
 
-def test_fused_adam_refreshes_transposed_copies_in_one_launch():
-    """After FusedAdam.step the cached W^T bf16 copies (rebuilt by vitmi_transpose_cast_multi) and the straight
-    copies match the updated fp32 parameters, for ragged and aligned shapes."""
-    from visiontransformer_amd import ops
+@pytest.mark.parametrize("tile_form", [True, False])
+def test_fused_adam_refreshes_transposed_copies(tile_form, monkeypatch):
+    """After FusedAdam.step the cached W^T bf16 copies and the straight copies match the updated fp32 parameters, for
+    ragged and aligned shapes: written by the tile form of the update itself (vitmi_adam_step_matrices: columns a
+    multiple of 4, rows a multiple of 4 or not, whole and partial 64 x 64 tiles) or, for the other matrices and with
+    the tile form switched off, by the transpose pass (vitmi_transpose_cast_multi).  Both forms leave the same bits in
+    the parameters and the optimizer state."""
+    from visiontransformer_amd import ops, optim
     from visiontransformer_amd.optim import FusedAdam
-    torch.manual_seed(0)
-    ps = [torch.nn.Parameter(torch.randn(r, c, device=DEV)) for r, c in [(96, 64), (33, 70), (256, 257), (5, 3)]]
-    ps.append(torch.nn.Parameter(torch.randn(17, device=DEV)))
-    opt = FusedAdam(ps, lr=1e-2)
-    for step in range(3):
-        straight = [ops.compute_copy(p, torch.bfloat16) for p in ps]
-        transposed = [ops.compute_copy_t(p, torch.bfloat16) for p in ps[:4]]
-        for p in ps:
-            p.grad = torch.randn_like(p)
-        before = [p.detach().clone() for p in ps]
-        opt.step()
-        for p, b, s in zip(ps, before, straight):
-            assert not torch.equal(p, b)
-            assert ops.compute_copy(p, torch.bfloat16) is s and torch.equal(s, p.detach().to(torch.bfloat16))
-        for p, t in zip(ps[:4], transposed):
-            assert ops.compute_copy_t(p, torch.bfloat16) is t                     # refreshed in place, not rebuilt
-            assert torch.equal(t, p.detach().t().contiguous().to(torch.bfloat16))
+    shapes = [(96, 64), (33, 70), (256, 257), (5, 3), (128, 100), (130, 68), (64, 192), (3, 8)]
+
+    def run(tile):
+        monkeypatch.setattr(optim, "TILE_ADAM", tile)
+        ops.clear_cast_cache()
+        torch.manual_seed(0)
+        ps = [torch.nn.Parameter(torch.randn(r, c, device=DEV)) for r, c in shapes]
+        ps.append(torch.nn.Parameter(torch.randn(17, device=DEV)))
+        opt = FusedAdam(ps, lr=1e-2, weight_decay=1e-2)
+        for step in range(3):
+            straight = [ops.compute_copy(p, torch.bfloat16) for p in ps]
+            transposed = [ops.compute_copy_t(p, torch.bfloat16) for p in ps[:len(shapes)]]
+            for p in ps:
+                p.grad = torch.randn_like(p)
+            before = [p.detach().clone() for p in ps]
+            opt.step()
+            for p, b, s in zip(ps, before, straight):
+                assert not torch.equal(p, b)
+                assert ops.compute_copy(p, torch.bfloat16) is s and torch.equal(s, p.detach().to(torch.bfloat16))
+            for p, t in zip(ps, transposed):
+                assert ops.compute_copy_t(p, torch.bfloat16) is t                 # refreshed in place, not rebuilt
+                assert torch.equal(t, p.detach().t().contiguous().to(torch.bfloat16))
+        return [p.detach().clone() for p in ps], [tuple(x.clone() for x in opt.state[p]) for p in ps]
+
+    params, state = run(tile_form)
+    if tile_form:
+        ref_params, ref_state = run(False)
+        for a, b in zip(params, ref_params):
+            assert torch.equal(a, b)
+        for (m1, v1), (m2, v2) in zip(state, ref_state):
+            assert torch.equal(m1, m2) and torch.equal(v1, v2)
 
 
 @pytest.mark.parametrize("N", [257, 384, 400, 577, 608])

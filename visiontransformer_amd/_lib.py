@@ -117,6 +117,7 @@ SIGNATURES = {
     "vitmi_dropout": (I, [P, P, I, L, F, U64, P]),
     "vitmi_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, F, I, F, P]),
     "vitmi_adam_step_multi": (I, [P, I, P, I, I, F, F, F, F, F, I, F, P]),
+    "vitmi_adam_step_matrices": (I, [P, P, I, L, F, F, F, F, F, I, F, P]),
 }
 
 

@@ -741,6 +741,80 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const vitmi_adam_tensor
     if (k < end) scalar(k);
 }
 
+// The same update for weight matrices that keep a transposed bf16 copy (the operand of the input-gradient GEMMs):
+// one block per 64 x 64 tile (found by bisection as in transpose_cast_multi_kernel) updates the tile 16 bytes per
+// access, writes the row-major bf16 copy, and sends the rounded values through LDS to write the transposed copy in
+// 8-byte pieces: the separate transpose pass and its re-read of every fp32 weight disappear.  cols % 4 == 0 and
+// 16-byte-aligned fp32 pointers are the caller's side of the contract (checked by the entry point).
+__global__ __launch_bounds__(256) void adam_tiles_kernel(const vitmi_adam_matrix* __restrict__ mats,
+                                                         const long long* __restrict__ tile_start, int n_mats,
+                                                         float lr_c, float b1, float b2, float eps, float wd,
+                                                         float bc2_sqrt, float gscale) {
+    __shared__ bf16_t tile[TT][TT + 2];
+    const long long t = blockIdx.x;
+    int lo = 0, hi = n_mats - 1;
+    while (lo < hi) {                   // last matrix whose first tile is <= t
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_start[mid] <= t) lo = mid;
+        else hi = mid - 1;
+    }
+    const vitmi_adam_matrix job = mats[lo];
+    float* __restrict__ p = job.param;
+    const float* __restrict__ g = job.grad;
+    float* __restrict__ m = job.exp_avg;
+    float* __restrict__ v = job.exp_avg_sq;
+    bf16_t* __restrict__ p16 = (bf16_t*)job.param_bf16;
+    bf16_t* __restrict__ p16t = (bf16_t*)job.param_bf16_t;
+    const int R = (int)job.rows, Cn = (int)job.cols;
+    const int tiles_c = (Cn + TT - 1) / TT;
+    const int local = (int)(t - tile_start[lo]);
+    const int c0 = (local % tiles_c) * TT, r0 = (local / tiles_c) * TT;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16; a thread owns 4 consecutive columns
+#pragma unroll
+    for (int k = ty; k < TT; k += 16) {
+        const int r = r0 + k, c = c0 + 4 * tx;
+        if (r < R && c < Cn) {
+            const long long i = (long long)r * Cn + c;
+            f32x4 pv = *reinterpret_cast<const f32x4*>(p + i);
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + i);
+            f32x4 mv = *reinterpret_cast<const f32x4*>(m + i);
+            f32x4 vv = *reinterpret_cast<const f32x4*>(v + i);
+            bf16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = pv[j], b = mv[j], cc = vv[j];
+                adam_update(a, gv[j], b, cc, lr_c, b1, b2, eps, wd, bc2_sqrt, gscale);
+                pv[j] = a;
+                mv[j] = b;
+                vv[j] = cc;
+                o[j] = (bf16_t)a;
+                tile[k][4 * tx + j] = o[j];
+            }
+            *reinterpret_cast<f32x4*>(p + i) = pv;
+            *reinterpret_cast<f32x4*>(m + i) = mv;
+            *reinterpret_cast<f32x4*>(v + i) = vv;
+            if (p16) *reinterpret_cast<bf16x4*>(p16 + i) = o;
+        }
+    }
+    __syncthreads();
+    const bool vec_t = (R & 3) == 0;
+#pragma unroll
+    for (int k = ty; k < TT; k += 16) {
+        const int c = c0 + k, r = r0 + 4 * tx;
+        if (c < Cn && r < R) {
+            bf16_t* dst = p16t + (long long)c * R + r;
+            if (vec_t) {
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = tile[4 * tx + j][k];
+                *reinterpret_cast<bf16x4*>(dst) = o;
+            } else {
+                for (int j = 0; j < 4 && r + j < R; ++j) dst[j] = tile[4 * tx + j][k];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // ================================================================ C ABI
@@ -1263,6 +1337,21 @@ extern "C" int vitmi_adam_step_multi(const vitmi_adam_tensor* tensors, int n_ten
     hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, s, tensors, chunks, chunk_elems, lr / bc1, beta1,
                        beta2, eps, weight_decay, bc2_sqrt, grad_scale);
     VITMI_LAUNCH_CHECK("vitmi_adam_step_multi");
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_adam_step_matrices(const vitmi_adam_matrix* mats, const long long* tile_start, int n_mats,
+                                        long long total_tiles, float lr, float beta1, float beta2, float eps,
+                                        float weight_decay, int step, float grad_scale, void* stream) {
+    VITMI_CHECK_ARG(n_mats >= 0 && total_tiles >= 0 && step >= 1, "vitmi_adam_step_matrices: bad argument");
+    if (n_mats == 0 || total_tiles == 0) return VITMI_OK;
+    VITMI_CHECK_ARG(mats && tile_start && total_tiles <= 0x7fffffffll, "vitmi_adam_step_matrices: bad table");
+    hipStream_t s = as_stream(stream);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_tiles_kernel, dim3((unsigned)total_tiles), dim3(256), 0, s, mats, tile_start, n_mats,
+                       lr / bc1, beta1, beta2, eps, weight_decay, bc2_sqrt, grad_scale);
+    VITMI_LAUNCH_CHECK("vitmi_adam_step_matrices");
     return VITMI_OK;
 }
 

@@ -1,9 +1,13 @@
 """Fused Adam over fp32 master parameters (torch.optim.Adam semantics, the optimizer of
 trainer.py:204-205) that refreshes the bf16 compute copies of the weights in the same pass.
 
-One launch updates every parameter tensor: a table of (param, grad, exp_avg, exp_avg_sq, bf16 copy, n)
+One launch updates every flat parameter tensor: a table of (param, grad, exp_avg, exp_avg_sq, bf16 copy, n)
 records and a table of (tensor, first element) chunks are uploaded each step (gradient buffers
-may move between steps) and `vitmi_adam_step_multi` gives one block to each chunk."""
+may move between steps) and `vitmi_adam_step_multi` gives one block to each chunk.  Weight matrices whose transposed
+bf16 copy is in use (the operand of the input-gradient products) go through `vitmi_adam_step_matrices`, a second
+launch with one block per 64 x 64 tile that writes both copies in the same pass."""
+import os
+
 import numpy as np
 import torch
 
@@ -11,6 +15,8 @@ from . import ops
 from ._lib import check, lib
 
 CHUNK = 65536  # elements per block
+# weight matrices with a transposed copy: update and both copies in one pass (VITMI_TILE_ADAM=0: flat + transpose pass)
+TILE_ADAM = os.environ.get("VITMI_TILE_ADAM", "1") != "0"
 
 
 class FusedAdam:
@@ -108,40 +114,77 @@ class FusedAdam:
                 launches.setdefault((p.device, gi, n), []).append(p)
         for (device, gi, nstep), plist in launches.items():
             group = self.param_groups[gi]
-            keep, g_ptr, p_ptr, p16_ptr, jobs = [], [], [], [], []
+            # weight matrices with a transposed bf16 copy take the tile form of the update, which writes that copy
+            # in the same pass; everything else (and a matrix the tile form's alignment contract does not fit)
+            # goes through the flat chunks, with a transpose pass afterwards for any such matrix
+            keep, flat, mats, jobs = [], [], [], []
             for p in plist:
                 g = p.grad.contiguous()
                 if g.dtype != torch.float32:
                     g = g.float()
                 keep.append(g)
-                g_ptr.append(g.data_ptr())
-                p_ptr.append(p.data_ptr())
                 hit = ops._cache_lookup((id(p), torch.bfloat16), p)
-                p16_ptr.append(hit.data_ptr() if hit is not None else 0)
-                # the transposed copy cannot be refreshed in the same pass: all of them go in one launch below
+                p16 = hit.data_ptr() if hit is not None else 0
                 hit_t = ops._cache_lookup((id(p), torch.bfloat16, "T"), p)
-                if hit_t is not None and p.dim() == 2 and p.dtype == torch.float32 and p.is_contiguous():
+                if hit_t is not None and p.dim() == 2:
+                    m, v = self._state(p)
+                    ptrs = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr())
+                    if (TILE_ADAM and p.shape[1] % 4 == 0 and all(a % 16 == 0 for a in ptrs) and p16 % 8 == 0
+                            and hit_t.data_ptr() % 8 == 0):
+                        mats.append((p, g.data_ptr(), p16, hit_t.data_ptr()))
+                        continue
                     jobs.append((p.data_ptr(), hit_t.data_ptr(), p.shape[0], p.shape[1]))
                 else:
                     ops._cast_cache.pop((id(p), torch.bfloat16, "T"), None)
-            recs, chunks = self._layout((device, gi), plist)
-            recs[:, 0] = p_ptr
-            recs[:, 1] = g_ptr
-            recs[:, 4] = p16_ptr
-            words = np.concatenate([recs.reshape(-1), chunks])
+                flat.append((p, g.data_ptr(), p16))
+            recs, chunks = self._layout((device, gi), [p for p, _, _ in flat])
+            if flat:
+                recs[:, 0] = [p.data_ptr() for p, _, _ in flat]
+                recs[:, 1] = [g for _, g, _ in flat]
+                recs[:, 4] = [c for _, _, c in flat]
+            mrecs, starts, total_tiles = self._layout_tiles((device, gi), [p for p, _, _, _ in mats])
+            if mats:
+                mrecs[:, 0] = [p.data_ptr() for p, _, _, _ in mats]
+                mrecs[:, 1] = [g for _, g, _, _ in mats]
+                mrecs[:, 4] = [c for _, _, c, _ in mats]
+                mrecs[:, 5] = [t for _, _, _, t in mats]
+            words = np.concatenate([recs.reshape(-1), chunks, mrecs.reshape(-1), starts])
+            hyper = (group["lr"], group["betas"][0], group["betas"][1], group["eps"], group["weight_decay"], nstep,
+                     grad_scale)
             with torch.cuda.device(device):
                 dev = self._upload(device, words)
-                check(lib.vitmi_adam_step_multi(dev.data_ptr(), len(plist), dev.data_ptr() + 8 * recs.size,
-                                                chunks.size // 2, CHUNK, group["lr"], group["betas"][0],
-                                                group["betas"][1], group["eps"], group["weight_decay"], nstep,
-                                                grad_scale, ops._stream()), "vitmi_adam_step_multi")
+                if flat:
+                    check(lib.vitmi_adam_step_multi(dev.data_ptr(), len(flat), dev.data_ptr() + 8 * recs.size,
+                                                    chunks.size // 2, CHUNK, *hyper, ops._stream()),
+                          "vitmi_adam_step_multi")
+                if mats:
+                    base = dev.data_ptr() + 8 * (recs.size + chunks.size)
+                    check(lib.vitmi_adam_step_matrices(base, base + 8 * mrecs.size, len(mats), total_tiles, *hyper,
+                                                       ops._stream()), "vitmi_adam_step_matrices")
                 if jobs:
                     tiles = [((r + 63) // 64) * ((c + 63) // 64) for _, _, r, c in jobs]
-                    starts = np.concatenate([[0], np.cumsum(tiles)[:-1]]).astype(np.int64)
-                    table = ops.upload(np.concatenate([np.asarray(jobs, dtype=np.int64).reshape(-1), starts]), device)
+                    tstarts = np.concatenate([[0], np.cumsum(tiles)[:-1]]).astype(np.int64)
+                    table = ops.upload(np.concatenate([np.asarray(jobs, dtype=np.int64).reshape(-1), tstarts]), device)
                     check(lib.vitmi_transpose_cast_multi(table.data_ptr(), table.data_ptr() + 32 * len(jobs), len(jobs),
                                                          int(sum(tiles)), ops._stream()), "vitmi_transpose_cast_multi")
             del keep
+
+    def _layout_tiles(self, device, plist):
+        """(records [len, 8] of vitmi_adam_matrix with the per-matrix constants filled in, first tile of each matrix,
+        total tiles) for this set of weight matrices; cached like _layout."""
+        key = ("tiles",) + tuple(id(p) for p in plist)
+        ent = self._layouts.get((device, key))
+        if ent is None:
+            recs = np.zeros((len(plist), 8), dtype=np.int64)
+            tiles = []
+            for ti, p in enumerate(plist):
+                m, v = self._state(p)
+                recs[ti, 2], recs[ti, 3], recs[ti, 6], recs[ti, 7] = m.data_ptr(), v.data_ptr(), p.shape[0], p.shape[1]
+                tiles.append(((p.shape[0] + 63) // 64) * ((p.shape[1] + 63) // 64))
+            starts = np.concatenate([[0], np.cumsum(tiles)[:-1]]).astype(np.int64) if tiles else np.zeros(0, np.int64)
+            ent = (recs, starts, int(sum(tiles)))
+            self._layouts[(device, key)] = ent
+        return ent
 
     def _layout(self, device, plist):
         """(records [len, 6] with the per-tensor constants filled in, chunk table) for this set of tensors; rebuilt
