@@ -168,6 +168,11 @@ int vitmi_debug_set_attn_head_groups(int on);
  * the next pair's operands under the current pair's products; 0: the dQ kernel and the dK/dV kernel, as for every
  * other shape.  Process-wide; benchmarking. */
 int vitmi_debug_set_attn_bwd_fused(int on);
+/* The fp32 attention kernels.  1 (default): products of 16 x 16 tiles on the fp32 matrix instruction (heads of 8 /
+ * 16 / 32 / 64, up to 288 tokens while two [tokens][head dim] images fit in LDS, 16-byte-aligned tensors), one launch
+ * forward and one backward, no workspace use; 0: the row-by-row kernels every other fp32 shape takes (the backward
+ * pass of those keeps P and dS in the workspace).  Same IEEE fp32 arithmetic either way.  Process-wide. */
+int vitmi_debug_set_attn_f32_mfma(int on);
 /* same for the weight-gradient (tn) GEMM: 0 = 128x128, 1 = 256x256, -1 = automatic */
 int vitmi_debug_set_tn_config(int cfg);
 

@@ -237,6 +237,33 @@ def test_attention_forward_backward(ops, dtype, B, N, H, DH):
     assert rel_err(dqkv, qr.grad) < TOL[dtype]
 
 
+@pytest.mark.parametrize("B,N,H,DH", ATTN_CASES + [(1, 40, 2, 24)])
+def test_attention_fp32_row_kernels(ops, B, N, H, DH):
+    """The row-by-row fp32 kernels (what an fp32 shape outside the matrix-instruction kernels' range takes, e.g. a
+    head dim of 24) against the fp32 expression, and the two families against each other where both apply."""
+    from visiontransformer_amd._lib import lib
+    dtype = torch.float32
+    qkv = rnd(B, N, 3 * H * DH, seed=11, scale=1.5)
+    do = rnd(B, N, H * DH, seed=12)
+    qr = q(qkv, dtype).requires_grad_(True)
+    o_ref, p_ref, lse_ref = attn_ref(qr, H, DH)
+    o_ref.backward(q(do, dtype))
+    qd, dod = qkv.to(DEV, dtype), do.to(DEV, dtype)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.vitmi_debug_set_attn_f32_mfma(mode)
+            o, lse, probs = ops.attn_fwd(qd, B, N, H, DH, True)
+            dqkv = ops.attn_bwd(qd, o, dod, lse, B, N, H, DH)
+            assert rel_err(o, o_ref) < 1e-4 and rel_err(probs, p_ref) < 1e-4 and rel_err(lse, lse_ref) < 1e-4
+            assert rel_err(dqkv, qr.grad) < 1e-4
+            res[mode] = (o, lse, probs, dqkv)
+    finally:
+        lib.vitmi_debug_set_attn_f32_mfma(1)
+    for a, b in zip(res[0], res[1]):
+        assert rel_err(a, b.cpu()) < 2e-5
+
+
 def test_attention_spiky_scores(ops):
     # one key dominates a row by a wide margin, another row is all-equal: exercises max-subtraction
     B, N, H, DH = 1, 70, 1, 64

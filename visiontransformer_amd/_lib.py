@@ -58,6 +58,7 @@ SIGNATURES = {
     "vitmi_debug_set_nt_tail_split": (I, [I]),
     "vitmi_debug_set_attn_head_groups": (I, [I]),
     "vitmi_debug_set_attn_bwd_fused": (I, [I]),
+    "vitmi_debug_set_attn_f32_mfma": (I, [I]),
     "vitmi_debug_set_gelu_pair": (I, [I]),
     "vitmi_set_gelu_mode": (I, [I]),
     "vitmi_get_gelu_mode": (I, []),

@@ -1544,6 +1544,271 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_f32_kernel(const float* __res
     }
 }
 
+// ================================================================ fp32 path on the fp32 matrix instruction
+// The same arithmetic (IEEE fp32 products and sums, expf / logf) as the row-by-row kernels above, as products of
+// 16 x 16 tiles through v_mfma_f32_16x16x4_f32: lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] of a
+// 16 x 4 / 4 x 16 step and receives D[4 (l >> 4) + r][l & 15].  One block per (image, head), a wave per 16-row tile.
+// Score tiles are formed transposed, S^T[key][query] = K Q^T, so that a lane's four values are four keys of ONE
+// query: they are exactly the B operand (P^T[key][query]) of the following product O^T = V^T P^T when the four steps
+// of a 16-key tile take the keys in the order 4 (l >> 4) + r, r = 0..3 -- a sum may run over its index in any order
+// as long as both operands agree -- so probabilities never leave registers.  The operand that changes with the tile
+// (K, V rows; Q, dO rows in the second half of the backward pass) is read from an LDS image [rows][LD], one element
+// per lane and step; the wave's own rows are fragments in registers.  Images hold 16 NT rows, zero past N and past
+// DH, LD = 16 ceil(DH / 16) + 4 floats.
+template <int DH>
+struct F32A {
+    static constexpr int DT = (DH + 15) / 16, W = 16 * DT, LD = W + 4, KS = DH / 4;
+};
+
+template <int DH>
+__device__ __forceinline__ void f32_stage(const float* __restrict__ src, long long ld, int N, int rows, float* img) {
+    using A = F32A<DH>;
+    constexpr int CPR = A::LD / 4;         // 16-byte pieces per LDS row
+    for (int c = threadIdx.x; c < rows * CPR; c += blockDim.x) {
+        const int r = c / CPR, k = (c - r * CPR) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < N && k < DH) v = *reinterpret_cast<const f32x4*>(src + (long long)r * ld + k);
+        *reinterpret_cast<f32x4*>(img + r * A::LD + k) = v;
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int DH, int NT>
+__global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                float* __restrict__ lse, float* __restrict__ probs,
+                                                                int N, int H, float scale) {
+    using A = F32A<DH>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* Ks = reinterpret_cast<float*>(smem);
+    float* Vs = Ks + 16 * NT * A::LD;
+    const int blk = xcd_block_order();
+    const int b = blk / H, h = blk % H;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const float* qb = qkv + (long long)b * N * ld + h * DH;
+    f32_stage<DH>(qb + I, ld, N, 16 * NT, Ks);
+    f32_stage<DH>(qb + 2 * I, ld, N, 16 * NT, Vs);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ntk = (N + 15) >> 4;
+    for (int qt = wave; qt < ntk; qt += 4) {
+        const int q = 16 * qt + fr;
+        float qf[A::KS];
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) qf[ks] = q < N ? qb[(long long)q * ld + 4 * ks + fk] : 0.f;
+        f32x4 st[NT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            st[c] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            if (c < ntk) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                const float* kr = Ks + (16 * c + fr) * A::LD + fk;
+#pragma unroll
+                for (int ks = 0; ks < A::KS; ++ks) acc = mfma4(kr[4 * ks], qf[ks], acc);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = (16 * c + 4 * fk + r < N) ? acc[r] * scale : -INFINITY;
+                    st[c][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(st[c][r] - mx);     // exp(-inf) = 0 for the keys past N
+                st[c][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        if (fk == 0 && q < N) lse[((long long)b * H + h) * N + q] = mx + logf(sum);
+#pragma unroll
+        for (int c = 0; c < NT; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[c][r] *= inv;
+        if (probs && q < N) {
+            float* prow = probs + (((long long)b * H + h) * N + q) * N;
+#pragma unroll
+            for (int c = 0; c < NT; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * c + 4 * fk + r;
+                    if (key < N) prow[key] = st[c][r];
+                }
+        }
+        f32x4 o[A::DT];
+#pragma unroll
+        for (int dt = 0; dt < A::DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            if (c < ntk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* vr = Vs + (16 * c + 4 * fk + r) * A::LD + fr;
+#pragma unroll
+                    for (int dt = 0; dt < A::DT; ++dt) o[dt] = mfma4(vr[16 * dt], st[c][r], o[dt]);
+                }
+            }
+        }
+        if (q < N) {
+            float* orow = out + ((long long)b * N + q) * I + h * DH;
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) {
+                const int d = 16 * dt + 4 * fk;
+                if (d < DH) *reinterpret_cast<f32x4*>(orow + d) = o[dt];
+            }
+        }
+    }
+}
+
+// Backward pass in one launch.  First half: a wave per query tile against the K and V images -- S^T and dP^T = V dO^T
+// tiles of all key tiles in registers, delta[q] = sum_k P dP from them, dS^T = P^T (dP^T - delta) / sqrt(dh), and
+// dQ^T = K^T dS^T; delta goes to LDS.  Second half: the images are rewritten with Q and dO, a wave per key tile forms
+// S = Q K^T and dP = dO V^T tiles (queries as rows now, so that the lane's four values are four queries of one key),
+// P from the stored row log-sum-exps, and accumulates dV^T = dO^T P and dK^T = Q^T dS over the query tiles.
+template <int DH, int NT>
+__global__ __launch_bounds__(256) void attn_bwd_f32_mfma_kernel(const float* __restrict__ qkv,
+                                                                const float* __restrict__ dout,
+                                                                const float* __restrict__ lse, float* __restrict__ dqkv,
+                                                                int N, int H, float scale) {
+    using A = F32A<DH>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* img0 = reinterpret_cast<float*>(smem);
+    float* img1 = img0 + 16 * NT * A::LD;
+    float* ls = img1 + 16 * NT * A::LD;      // row log-sum-exp, a large value past N (the probability becomes 0)
+    float* dl = ls + 16 * NT;                // delta
+    const int blk = xcd_block_order();
+    const int b = blk / H, h = blk % H;
+    const int I = H * DH;
+    const long long ld = 3ll * I;
+    const float* qb = qkv + (long long)b * N * ld + h * DH;
+    const float* dob = dout + (long long)b * N * I + h * DH;
+    float* gb = dqkv + (long long)b * N * ld + h * DH;
+    f32_stage<DH>(qb + I, ld, N, 16 * NT, img0);
+    f32_stage<DH>(qb + 2 * I, ld, N, 16 * NT, img1);
+    for (int t = threadIdx.x; t < 16 * NT; t += blockDim.x) ls[t] = t < N ? lse[((long long)b * H + h) * N + t] : 1e30f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ntk = (N + 15) >> 4;
+    for (int qt = wave; qt < ntk; qt += 4) {
+        const int q = 16 * qt + fr;
+        float qf[A::KS], dof[A::KS];
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) {
+            qf[ks] = q < N ? qb[(long long)q * ld + 4 * ks + fk] : 0.f;
+            dof[ks] = q < N ? dob[(long long)q * I + 4 * ks + fk] : 0.f;
+        }
+        const float lq = ls[q];
+        f32x4 pt[NT], dpt[NT];
+        float dsum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            pt[c] = dpt[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < ntk) {
+                f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+                const float* kr = img0 + (16 * c + fr) * A::LD + fk;
+                const float* vr = img1 + (16 * c + fr) * A::LD + fk;
+#pragma unroll
+                for (int ks = 0; ks < A::KS; ++ks) {
+                    sa = mfma4(kr[4 * ks], qf[ks], sa);
+                    da = mfma4(vr[4 * ks], dof[ks], da);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = (16 * c + 4 * fk + r < N) ? expf(sa[r] * scale - lq) : 0.f;
+                    pt[c][r] = pv;
+                    dpt[c][r] = da[r];
+                    dsum += pv * da[r];
+                }
+            }
+        }
+        dsum += __shfl_xor(dsum, 16, 64);
+        dsum += __shfl_xor(dsum, 32, 64);
+        if (fk == 0) dl[q] = dsum;
+        f32x4 dq[A::DT];
+#pragma unroll
+        for (int dt = 0; dt < A::DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            if (c < ntk) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dsv = pt[c][r] * (dpt[c][r] - dsum) * scale;
+                    const float* kr = img0 + (16 * c + 4 * fk + r) * A::LD + fr;
+#pragma unroll
+                    for (int dt = 0; dt < A::DT; ++dt) dq[dt] = mfma4(kr[16 * dt], dsv, dq[dt]);
+                }
+            }
+        }
+        if (q < N) {
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) {
+                const int d = 16 * dt + 4 * fk;
+                if (d < DH) *reinterpret_cast<f32x4*>(gb + (long long)q * ld + d) = dq[dt];
+            }
+        }
+    }
+    __syncthreads();   // every wave is through with the K and V images; delta is complete
+    f32_stage<DH>(qb, ld, N, 16 * NT, img0);
+    f32_stage<DH>(dob, I, N, 16 * NT, img1);
+    __syncthreads();
+    for (int kt = wave; kt < ntk; kt += 4) {
+        const int key = 16 * kt + fr;
+        float kf[A::KS], vf[A::KS];
+#pragma unroll
+        for (int ks = 0; ks < A::KS; ++ks) {
+            kf[ks] = key < N ? qb[(long long)key * ld + I + 4 * ks + fk] : 0.f;
+            vf[ks] = key < N ? qb[(long long)key * ld + 2 * I + 4 * ks + fk] : 0.f;
+        }
+        f32x4 dk[A::DT], dv[A::DT];
+#pragma unroll
+        for (int dt = 0; dt < A::DT; ++dt) dk[dt] = dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int qc = 0; qc < ntk; ++qc) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
+            const float* qr = img0 + (16 * qc + fr) * A::LD + fk;
+            const float* dr = img1 + (16 * qc + fr) * A::LD + fk;
+#pragma unroll
+            for (int ks = 0; ks < A::KS; ++ks) {
+                sa = mfma4(qr[4 * ks], kf[ks], sa);
+                da = mfma4(dr[4 * ks], vf[ks], da);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = 16 * qc + 4 * fk + r;
+                const float pv = expf(sa[r] * scale - ls[qq]);
+                const float dsv = pv * (da[r] - dl[qq]) * scale;
+                const float* qrow = img0 + qq * A::LD + fr;
+                const float* drow = img1 + qq * A::LD + fr;
+#pragma unroll
+                for (int dt = 0; dt < A::DT; ++dt) {
+                    dv[dt] = mfma4(drow[16 * dt], pv, dv[dt]);
+                    dk[dt] = mfma4(qrow[16 * dt], dsv, dk[dt]);
+                }
+            }
+        }
+        if (key < N) {
+#pragma unroll
+            for (int dt = 0; dt < A::DT; ++dt) {
+                const int d = 16 * dt + 4 * fk;
+                if (d < DH) {
+                    *reinterpret_cast<f32x4*>(gb + (long long)key * ld + I + d) = dk[dt];
+                    *reinterpret_cast<f32x4*>(gb + (long long)key * ld + 2 * I + d) = dv[dt];
+                }
+            }
+        }
+    }
+}
+
 // ================================================================ gradient arriving at the exported probabilities
 // One (image, head): dS[q][j] = P[q][j] * (dP[q][j] - sum_j' P[q][j'] dP[q][j']) * scale with P recomputed from the
 // fp32 scores S = q k^T and the row's log-sum-exp (softmax backward for a gradient dP that reaches the probabilities
@@ -1772,6 +2037,72 @@ inline size_t f32_fwd_smem(int N, int DH) { return ((size_t)2 * N * (DH + 1) + 4
 inline size_t f32_bwdq_smem(int N, int DH) { return ((size_t)2 * N * (DH + 1) + 8 * DH + 4 * N) * sizeof(float); }
 inline size_t f32_bwdkv_smem(int N, int DH) { return ((size_t)2 * N * (DH + 1)) * sizeof(float); }
 
+// the fp32 kernels on the matrix instruction: heads of 8 / 16 / 32 / 64, up to 18 key tiles, both images in LDS,
+// 16-byte-aligned rows (every row of a head starts a multiple of 4 floats into a 16-byte-aligned tensor)
+int g_attn_f32_mfma = 1;
+template <int DH> constexpr size_t f32_mfma_lds(int nt, bool bwd) {
+    return ((size_t)2 * 16 * nt * F32A<DH>::LD + (bwd ? 2 * 16 * nt : 0)) * sizeof(float);
+}
+inline int f32_mfma_tiles(int N) {
+    const int nt = (N + 15) >> 4;
+    return nt <= 5 ? 5 : (nt <= 9 ? 9 : (nt <= 13 ? 13 : (nt <= 18 ? 18 : 0)));
+}
+inline bool f32_mfma_ok(int N, int DH, bool bwd, const void* p0, const void* p1, const void* p2, const void* p3) {
+    if (!g_attn_f32_mfma || !(DH == 8 || DH == 16 || DH == 32 || DH == 64)) return false;
+    const int nt = f32_mfma_tiles(N);
+    if (!nt) return false;
+    const size_t ldw = 16 * ((DH + 15) / 16) + 4;
+    if (((size_t)2 * 16 * nt * ldw + (bwd ? 2 * 16 * nt : 0)) * sizeof(float) > 160 * 1024) return false;
+    const uintptr_t u = reinterpret_cast<uintptr_t>(p0) | reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2) |
+                        reinterpret_cast<uintptr_t>(p3);
+    return (u & 15) == 0;
+}
+template <int DH, int NT>
+int launch_fwd_f32_mfma(const float* qkv, float* out, float* lse, float* probs, int B, int N, int H, hipStream_t s) {
+    static unsigned long long done = 0;
+    const size_t sm = f32_mfma_lds<DH>(NT, false);
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_fwd_f32_mfma_kernel<DH, NT>), sm, &done, "vitmi_attn_fwd: LDS attribute (f32)");
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL((attn_fwd_f32_mfma_kernel<DH, NT>), dim3(B * H), dim3(256), sm, s, qkv, out, lse, probs, N, H,
+                       1.0f / sqrtf((float)DH));
+    VITMI_LAUNCH_CHECK("vitmi_attn_fwd(f32, mfma)");
+    return VITMI_OK;
+}
+template <int DH, int NT>
+int launch_bwd_f32_mfma(const float* qkv, const float* dout, const float* lse, float* dqkv, int B, int N, int H,
+                        hipStream_t s) {
+    static unsigned long long done = 0;
+    const size_t sm = f32_mfma_lds<DH>(NT, true);
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_bwd_f32_mfma_kernel<DH, NT>), sm, &done, "vitmi_attn_bwd: LDS attribute (f32)");
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL((attn_bwd_f32_mfma_kernel<DH, NT>), dim3(B * H), dim3(256), sm, s, qkv, dout, lse, dqkv, N, H,
+                       1.0f / sqrtf((float)DH));
+    VITMI_LAUNCH_CHECK("vitmi_attn_bwd(f32, mfma)");
+    return VITMI_OK;
+}
+#define DISPATCH_F32_MFMA(FN, ...)                                     \
+    do {                                                               \
+        const int nt_ = f32_mfma_tiles(N);                             \
+        switch (DH * 100 + nt_) {                                      \
+            case 805: return FN<8, 5>(__VA_ARGS__);                    \
+            case 809: return FN<8, 9>(__VA_ARGS__);                    \
+            case 813: return FN<8, 13>(__VA_ARGS__);                   \
+            case 818: return FN<8, 18>(__VA_ARGS__);                   \
+            case 1605: return FN<16, 5>(__VA_ARGS__);                  \
+            case 1609: return FN<16, 9>(__VA_ARGS__);                  \
+            case 1613: return FN<16, 13>(__VA_ARGS__);                 \
+            case 1618: return FN<16, 18>(__VA_ARGS__);                 \
+            case 3205: return FN<32, 5>(__VA_ARGS__);                  \
+            case 3209: return FN<32, 9>(__VA_ARGS__);                  \
+            case 3213: return FN<32, 13>(__VA_ARGS__);                 \
+            case 3218: return FN<32, 18>(__VA_ARGS__);                 \
+            case 6405: return FN<64, 5>(__VA_ARGS__);                  \
+            case 6409: return FN<64, 9>(__VA_ARGS__);                  \
+            case 6413: return FN<64, 13>(__VA_ARGS__);                 \
+            default: return FN<64, 18>(__VA_ARGS__);                   \
+        }                                                              \
+    } while (0)
+
 int check_common(const char* who, int dt, int B, int N, int H, int DH) {
     VITMI_CHECK_ARG(dt == VITMI_F32 || dt == VITMI_BF16, "%s: bad dtype %d", who, dt);
     VITMI_CHECK_ARG(B > 0 && N > 0 && H > 0 && DH > 0, "%s: bad shape B=%d N=%d H=%d DH=%d", who, B, N, H, DH);
@@ -1796,6 +2127,11 @@ int check_common(const char* who, int dt, int B, int N, int H, int DH) {
 
 extern "C" int vitmi_debug_set_attn_head_groups(int on) {
     g_attn_head_groups = on;
+    return VITMI_OK;
+}
+
+extern "C" int vitmi_debug_set_attn_f32_mfma(int on) {
+    g_attn_f32_mfma = on ? 1 : 0;
     return VITMI_OK;
 }
 
@@ -1824,6 +2160,8 @@ extern "C" int vitmi_attn_fwd(const void* qkv, void* out, float* lse, void* prob
     tl_qT = (layout & VITMI_QKV_HEAD_MAJOR) ? (long long)B * N : 0;
     hipStream_t s = as_stream(stream);
     ProfScope prof(VITMI_FAM_ATTN_FWD, s, 4.0 * B * H * (double)N * N * DH);
+    if (dt == VITMI_F32 && f32_mfma_ok(N, DH, false, qkv, out, nullptr, nullptr))
+        DISPATCH_F32_MFMA(launch_fwd_f32_mfma, (const float*)qkv, (float*)out, lse, (float*)probs, B, N, H, s);
     if (dt == VITMI_F32) {
         const size_t sm = f32_fwd_smem(N, DH);
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_f32_kernel),
@@ -1913,6 +2251,8 @@ static int attn_bwd_from_dout(const void* qkv, const void* out, const void* dout
                               void* workspace, int dt, int B, int N, int H, int DH, hipStream_t s) {
     // five products of the flash-style backward: 10 * B * H * N^2 * DH
     ProfScope prof(VITMI_FAM_ATTN_BWD, s, 10.0 * B * H * (double)N * N * DH);
+    if (dt == VITMI_F32 && f32_mfma_ok(N, DH, true, qkv, dout, dqkv, nullptr))
+        DISPATCH_F32_MFMA(launch_bwd_f32_mfma, (const float*)qkv, (const float*)dout, lse, (float*)dqkv, B, N, H, s);
     if (dt == VITMI_F32) {
         VITMI_CHECK_ARG(workspace, "vitmi_attn_bwd: fp32 path needs a workspace");
         float* Pw = (float*)workspace;

@@ -294,17 +294,22 @@ struct F32Operand {
 // 64 x 64 output tile per 4-wave block, each wave a 32 x 32 quarter as 2 x 2 v_mfma_f32_16x16x4_f32 tiles (IEEE fp32
 // products and sums: the exact-arithmetic mode keeps its 1e-4 bar).  Operand fragments of that instruction: lane l
 // supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] of a 16 x 4 / 4 x 16 step and receives D[4 (l >> 4) + i][l & 15].
-// Both tiles sit in LDS as [row][k] with rows 17 floats apart.
+// Both tiles sit in LDS as [row][k], 32-deep, rows 36 floats apart.
 // blockIdx.z walks K in chunks of k_chunk (weight gradients: K = tokens, few output tiles): slab z of the partial
 // products goes to C + z * slab_stride and f32_slab_sum_kernel adds the slabs in index order.
+//
+// A thread fetches its share of a K-tile as 16-byte pieces along whichever index its operand is contiguous in (k for
+// x and the weights of a forward product, the row for the column-major views of the backward products), when base,
+// strides and extent allow it (va / vb), and as single elements otherwise.  The next K-tile is in flight while the
+// current one's products are issued.
 template <int EPI, int T = 64>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand B, Epilogue epi, int M, int N, int K,
-                                                       int k_chunk, long long slab_stride) {
+                                                       int k_chunk, long long slab_stride, int va, int vb) {
     // T x T output tile: 64 (each wave a 32 x 32 quarter, 2 x 2 MFMA tiles) or, for products of few tiles (the
     // classifier head: 256 x 100 outputs), 32 (each wave one 16 x 16 tile: four times the blocks)
-    constexpr int TK = 16, LD = TK + 1, PER = T * TK / 256, SUB = T / 32;
-    __shared__ float As[T][LD];
-    __shared__ float Bs[T][LD];
+    constexpr int TK = 32, LD = TK + 4, PER = T * TK / 256, PV = PER / 4, SUB = T / 32;
+    __shared__ __attribute__((aligned(16))) float As[T][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[T][LD];
     const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
     const int kz0 = blockIdx.z * k_chunk, kz1 = min(K, kz0 + k_chunk);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -317,33 +322,78 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand 
     for (int i = 0; i < SUB; ++i)
 #pragma unroll
         for (int j = 0; j < SUB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // the next tile's elements are requested before the current tile's products are issued
-    float av[PER], bv[PER];
-    auto fetch = [&](int k0) {
+    // piece i of a thread: 4 consecutive k of one row (kc) or 4 consecutive rows at one k; as scalars: element
+    // c = tid + 256 i in the same (row, k) enumeration the single-element form always used
+    auto piece_at = [&](bool kc, int i, int& r, int& k) {
+        const int c = threadIdx.x + i * 256;
+        if (kc) { k = 4 * (c & 7); r = c >> 3; } else { r = 4 * (c % (T / 4)); k = c / (T / 4); }
+    };
+    auto elem_at = [&](bool kc, int i, int& r, int& k) {
+        const int c = threadIdx.x + i * 256;
+        if (kc) { k = c & 31; r = c >> 5; } else { r = c % T; k = c / T; }
+    };
+    auto fetch_op = [&](const F32Operand& X, bool kc, int vec, int row0, int k0, float (&dst)[PER]) {
+        if (vec) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int c = threadIdx.x + i * 256;
-            int r, k;
-            if (a_kc) { k = c & 15; r = c >> 4; } else { r = c % T; k = c / T; }
-            av[i] = A.at(m0 + r, k0 + k, kz1);
-            if (b_kc) { k = c & 15; r = c >> 4; } else { r = c % T; k = c / T; }
-            bv[i] = B.at(n0 + r, k0 + k, kz1);
+            for (int i = 0; i < PV; ++i) {
+                int r, k;
+                piece_at(kc, i, r, k);
+                const int gr = row0 + r, gk = k0 + k;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kc ? (gr < X.R && gk + 3 < kz1) : (gr + 3 < X.R && gk < kz1)) {
+                    v = *reinterpret_cast<const f32x4*>(X.p + (long long)gr * X.s_r + (long long)gk * X.s_k);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = kc ? X.at(gr, gk + j, kz1) : X.at(gr + j, gk, kz1);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[4 * i + j] = v[j];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                int r, k;
+                elem_at(kc, i, r, k);
+                dst[i] = X.at(row0 + r, k0 + k, kz1);
+            }
         }
     };
-    if (kz0 < kz1) fetch(kz0);
+    auto put_op = [&](float (&S)[T][LD], bool kc, int vec, const float (&src)[PER]) {
+        if (vec) {
+#pragma unroll
+            for (int i = 0; i < PV; ++i) {
+                int r, k;
+                piece_at(kc, i, r, k);
+                if (kc) {
+                    *reinterpret_cast<f32x4*>(&S[r][k]) = f32x4{src[4 * i], src[4 * i + 1], src[4 * i + 2], src[4 * i + 3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) S[r + j][k] = src[4 * i + j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                int r, k;
+                elem_at(kc, i, r, k);
+                S[r][k] = src[i];
+            }
+        }
+    };
+    float av[PER], bv[PER];
+    if (kz0 < kz1) {
+        fetch_op(A, a_kc, va, m0, kz0, av);
+        fetch_op(B, b_kc, vb, n0, kz0, bv);
+    }
     for (int k0 = kz0; k0 < kz1; k0 += TK) {
         __syncthreads();  // the previous tile's fragments have been read
-#pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int c = threadIdx.x + i * 256;
-            int r, k;
-            if (a_kc) { k = c & 15; r = c >> 4; } else { r = c % T; k = c / T; }
-            As[r][k] = av[i];
-            if (b_kc) { k = c & 15; r = c >> 4; } else { r = c % T; k = c / T; }
-            Bs[r][k] = bv[i];
-        }
+        put_op(As, a_kc, va, av);
+        put_op(Bs, b_kc, vb, bv);
         __syncthreads();
-        if (k0 + TK < kz1) fetch(k0 + TK);
+        if (k0 + TK < kz1) {
+            fetch_op(A, a_kc, va, m0, k0 + TK, av);
+            fetch_op(B, b_kc, vb, n0, k0 + TK, bv);
+        }
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 4) {
             float a[SUB], b[SUB];
@@ -371,6 +421,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand 
                 if (n < N) epilogue_store<EPI, float, float>(epi, m, n, acc[i][j][r]);
             }
         }
+}
+
+// 16-byte pieces of an fp32 operand: contiguous along k (s_k == 1) or along the row (s_r == 1), the other stride a
+// multiple of 4 elements, the base 16-byte aligned; patch operands and everything else go element by element
+inline int f32_vec_ok(const F32Operand& x) {
+    if (x.patch || (reinterpret_cast<uintptr_t>(x.p) & 15)) return 0;
+    if (x.s_k == 1) return x.s_r % 4 == 0;
+    if (x.s_r == 1) return x.s_k % 4 == 0;
+    return 0;
 }
 
 // out[m * ldc + n] = sum_z slabs[z][m][n] (dense M x N slabs), in slab order
@@ -401,16 +460,16 @@ inline int launch_f32_plain(const F32Operand& a, const F32Operand& b, Epilogue e
     int splits = slabs ? f32_k_splits(M, N, K) : 1;
     int chunk = K;
     if (splits > 1) {
-        chunk = ((K + splits - 1) / splits + 15) / 16 * 16;
+        chunk = ((K + splits - 1) / splits + 31) / 32 * 32;
         splits = (K + chunk - 1) / chunk;
     }
     dim3 grid(ceil_div(N, 64), ceil_div(M, 64), splits);
     if (splits <= 1) {
         if ((long long)grid.x * grid.y < 128)
             hipLaunchKernelGGL((gemm_f32_kernel<VITMI_EPI_NONE, 32>), dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, s, a, b,
-                               epi, M, N, K, K, 0ll);
+                               epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
         else
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
         VITMI_LAUNCH_CHECK(what);
         return VITMI_OK;
     }
@@ -418,7 +477,7 @@ inline int launch_f32_plain(const F32Operand& a, const F32Operand& b, Epilogue e
     const long long ldc = epi.ldc;
     epi.C = slabs;
     epi.ldc = N;
-    hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, chunk, (long long)M * N);
+    hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, chunk, (long long)M * N, f32_vec_ok(a), f32_vec_ok(b));
     VITMI_LAUNCH_CHECK(what);
     const int blocks = (int)std::min<long long>(((long long)M * N + 255) / 256, 1024);
     hipLaunchKernelGGL(f32_slab_sum_kernel, dim3(blocks), dim3(256), 0, s, slabs, splits, M, N, out, ldc);
@@ -496,13 +555,13 @@ static int gemm_impl(int dt, int M, int N, int K, const void* A, long long sam, 
         if (epilogue == VITMI_EPI_NONE)
             return launch_f32_plain(a, b, epi, M, N, K, nullptr, s, "vitmi_gemm(f32)");
         else if (epilogue == VITMI_EPI_GELU)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
         else if (epilogue == VITMI_EPI_GELU_D)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU_D>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU_D>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
         else if (epilogue == VITMI_EPI_MULAUX)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_MULAUX>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_MULAUX>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
         else
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_DGELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
+            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_DGELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
         VITMI_LAUNCH_CHECK("vitmi_gemm(f32)");
         return VITMI_OK;
     }
@@ -598,7 +657,7 @@ extern "C" int vitmi_patch_embed_fwd(const void* x, int x_dt, const void* w, con
         F32Operand a{(const float*)x, 0, 0, M, 1, 1, C, H, W, p, gw, gh};
         F32Operand b{(const float*)w, K, 1, N, 0, 0, 0, 0, 0, 0, 0, 0};
         dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
-        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll);
+        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
         VITMI_LAUNCH_CHECK("vitmi_patch_embed_fwd(f32)");
         return VITMI_OK;
     }
