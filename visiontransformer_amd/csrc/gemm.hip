@@ -443,6 +443,21 @@ __global__ void f32_slab_sum_kernel(const float* __restrict__ slabs, int nslabs,
     }
 }
 
+// Below this many 64 x 64 tiles (four blocks per CU) a product runs on 32 x 32 tiles: a block's K-loop is a chain of
+// load latencies, and four times the blocks is four times the chains in flight (cfg 1 step: 4.94 -> 4.49 ms).
+constexpr long long F32_SMALL_BELOW = 1024;
+
+template <int EPI>
+inline void launch_f32_epi(const F32Operand& a, const F32Operand& b, const Epilogue& epi, int M, int N, int K, hipStream_t s) {
+    const dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+    if ((long long)grid.x * grid.y < F32_SMALL_BELOW)
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI, 32>), dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, s, a, b, epi, M, N,
+                           K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI, 64>), grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a),
+                           f32_vec_ok(b));
+}
+
 // K chunks for an fp32 product whose output has few tiles (weight gradients): enough blocks for two per CU, chunks of
 // at least 256.  A function of the shape alone, so that the workspace query and the launch agree.
 inline int f32_k_splits(int M, int N, int K) {
@@ -465,7 +480,7 @@ inline int launch_f32_plain(const F32Operand& a, const F32Operand& b, Epilogue e
     }
     dim3 grid(ceil_div(N, 64), ceil_div(M, 64), splits);
     if (splits <= 1) {
-        if ((long long)grid.x * grid.y < 128)
+        if ((long long)grid.x * grid.y < F32_SMALL_BELOW)
             hipLaunchKernelGGL((gemm_f32_kernel<VITMI_EPI_NONE, 32>), dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, s, a, b,
                                epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
         else
@@ -477,7 +492,12 @@ inline int launch_f32_plain(const F32Operand& a, const F32Operand& b, Epilogue e
     const long long ldc = epi.ldc;
     epi.C = slabs;
     epi.ldc = N;
-    hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, chunk, (long long)M * N, f32_vec_ok(a), f32_vec_ok(b));
+    if ((long long)grid.x * grid.y * grid.z < F32_SMALL_BELOW)
+        hipLaunchKernelGGL((gemm_f32_kernel<VITMI_EPI_NONE, 32>), dim3(ceil_div(N, 32), ceil_div(M, 32), splits), dim3(256), 0, s,
+                           a, b, epi, M, N, K, chunk, (long long)M * N, f32_vec_ok(a), f32_vec_ok(b));
+    else
+        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, chunk, (long long)M * N,
+                           f32_vec_ok(a), f32_vec_ok(b));
     VITMI_LAUNCH_CHECK(what);
     const int blocks = (int)std::min<long long>(((long long)M * N + 255) / 256, 1024);
     hipLaunchKernelGGL(f32_slab_sum_kernel, dim3(blocks), dim3(256), 0, s, slabs, splits, M, N, out, ldc);
@@ -555,13 +575,13 @@ static int gemm_impl(int dt, int M, int N, int K, const void* A, long long sam, 
         if (epilogue == VITMI_EPI_NONE)
             return launch_f32_plain(a, b, epi, M, N, K, nullptr, s, "vitmi_gemm(f32)");
         else if (epilogue == VITMI_EPI_GELU)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
+            launch_f32_epi<VITMI_EPI_GELU>(a, b, epi, M, N, K, s);
         else if (epilogue == VITMI_EPI_GELU_D)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_GELU_D>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
+            launch_f32_epi<VITMI_EPI_GELU_D>(a, b, epi, M, N, K, s);
         else if (epilogue == VITMI_EPI_MULAUX)
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_MULAUX>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
+            launch_f32_epi<VITMI_EPI_MULAUX>(a, b, epi, M, N, K, s);
         else
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_DGELU>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
+            launch_f32_epi<VITMI_EPI_DGELU>(a, b, epi, M, N, K, s);
         VITMI_LAUNCH_CHECK("vitmi_gemm(f32)");
         return VITMI_OK;
     }
