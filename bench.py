@@ -49,6 +49,8 @@ WORKLOADS = {
     # BASELINE config 1: mymodel/ViT.py on config/cifar10 with the 32x32 / patch 4 overrides (UMAP.py:12-17), batch 64,
     # fp32 as trainer.py runs it
     "cifar10_cpu": (dict(CIFAR, num_classes=10), "plain_f32", 64, 1.327),
+    # the metric's geometry in the reference's own arithmetic (trainer.py trains in fp32): the exact mode of the library
+    "vit_b16_224_f32": (VITB, "plain_f32", 256, 105.378822144),
     # BASELINE config 2: CIFAR-100 geometry, bf16, with the attention-map export mia_attn.py consumes
     "cifar100_export": (dict(CIFAR, num_classes=100), "export", 256, 1.327),
     # BASELINE config 3: ViT_mask / PEdrop, a new BEiT block mask every step (32 of 64 patches)

@@ -305,8 +305,9 @@ struct F32Operand {
 template <int EPI, int T = 64>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand B, Epilogue epi, int M, int N, int K,
                                                        int k_chunk, long long slab_stride, int va, int vb) {
-    // T x T output tile: 64 (each wave a 32 x 32 quarter, 2 x 2 MFMA tiles) or, for products of few tiles (the
-    // classifier head: 256 x 100 outputs), 32 (each wave one 16 x 16 tile: four times the blocks)
+    // T x T output tile: 128 for large products (each wave a 64 x 64 quarter, 4 x 4 MFMA tiles: half the LDS reads
+    // per product of the 64 tile), 64 (2 x 2), or, for products of few tiles, 32 (each wave one 16 x 16 tile: four
+    // times the blocks)
     constexpr int TK = 32, LD = TK + 4, PER = T * TK / 256, PV = PER / 4, SUB = T / 32;
     __shared__ __attribute__((aligned(16))) float As[T][LD];
     __shared__ __attribute__((aligned(16))) float Bs[T][LD];
@@ -394,18 +395,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(F32Operand A, F32Operand 
             fetch_op(A, a_kc, va, m0, k0 + TK, av);
             fetch_op(B, b_kc, vb, n0, k0 + TK, bv);
         }
+        // A lane reads its row's k = 8 fk .. 8 fk + 7 as two 16-byte pieces; step (h, j) of the eight takes element
+        // 4 h + j from every lane, so the four lane groups supply k = 8 fk + 4 h + j, four different k, to both
+        // operands alike (a sum may take its index in any order).  Rows are 36 floats apart: the sixteen rows of a
+        // piece fall on all 64 banks once.
 #pragma unroll
-        for (int kk = 0; kk < TK; kk += 4) {
-            float a[SUB], b[SUB];
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a[SUB], b[SUB];
 #pragma unroll
             for (int i = 0; i < SUB; ++i) {
-                a[i] = As[wm + 16 * i + fr][kk + fk];
-                b[i] = Bs[wn + 16 * i + fr][kk + fk];
+                a[i] = *reinterpret_cast<const f32x4*>(&As[wm + 16 * i + fr][8 * fk + 4 * h]);
+                b[i] = *reinterpret_cast<const f32x4*>(&Bs[wn + 16 * i + fr][8 * fk + 4 * h]);
             }
 #pragma unroll
-            for (int i = 0; i < SUB; ++i)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < SUB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < SUB; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < SUB; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], b[jj][j], acc[i][jj], 0, 0, 0);
         }
     }
     if (slab_stride > 0) epi.C = reinterpret_cast<float*>(epi.C) + (long long)blockIdx.z * slab_stride;
@@ -443,19 +451,168 @@ __global__ void f32_slab_sum_kernel(const float* __restrict__ slabs, int nslabs,
     }
 }
 
-// Below this many 64 x 64 tiles (four blocks per CU) a product runs on 32 x 32 tiles: a block's K-loop is a chain of
-// load latencies, and four times the blocks is four times the chains in flight (cfg 1 step: 4.94 -> 4.49 ms).
+// The same product for operands that can be fetched 16 bytes at a time throughout: every operand either contiguous
+// along k (AKC / BKC: the activations and weights of a forward product) or along its row index (the column-major
+// views the backward products take), bases 16-byte aligned, the other stride a multiple of 4, K and the K chunk
+// multiples of 32, row counts of row-contiguous operands multiples of 4.  Per-thread source pointers are set up once
+// and advanced by a constant, so the K-loop carries no index arithmetic and the kernel needs half the registers of
+// the generic one; rows past the edge are fetched as zeros.
+template <int EPI, int T, bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f32_vec_kernel(const float* __restrict__ Ap, long long a_ld, int AR,
+                                                           const float* __restrict__ Bp, long long b_ld, int BR,
+                                                           Epilogue epi, int M, int N, int K, int k_chunk,
+                                                           long long slab_stride) {
+    constexpr int TK = 32, LD = TK + 4, PV = T * TK / 1024, SUB = T / 32;
+    __shared__ __attribute__((aligned(16))) float As[T][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[T][LD];
+    const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+    const int kz0 = blockIdx.z * k_chunk, kz1 = min(K, kz0 + k_chunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * (T / 2), wn = (wave & 1) * (T / 2);
+    const int fr = lane & 15, fk = lane >> 4;
+    f32x4 acc[SUB][SUB];
+#pragma unroll
+    for (int i = 0; i < SUB; ++i)
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // piece i of a thread: 4 consecutive k of one row (k-contiguous operand) or 4 consecutive rows at one k
+    auto piece = [&](bool kc, int i, int& r, int& k) {
+        const int c = threadIdx.x + i * 256;
+        if (kc) { k = 4 * (c & 7); r = c >> 3; } else { r = 4 * (c % (T / 4)); k = c / (T / 4); }
+    };
+    const float* ap[PV];
+    const float* bp[PV];
+    unsigned aok = 0, bok = 0;
+#pragma unroll
+    for (int i = 0; i < PV; ++i) {
+        int r, k;
+        piece(AKC, i, r, k);
+        ap[i] = AKC ? Ap + (long long)(m0 + r) * a_ld + kz0 + k : Ap + (m0 + r) + (long long)(kz0 + k) * a_ld;
+        if (m0 + r < AR) aok |= 1u << i;
+        piece(BKC, i, r, k);
+        bp[i] = BKC ? Bp + (long long)(n0 + r) * b_ld + kz0 + k : Bp + (n0 + r) + (long long)(kz0 + k) * b_ld;
+        if (n0 + r < BR) bok |= 1u << i;
+    }
+    const long long a_step = AKC ? TK : TK * a_ld, b_step = BKC ? TK : TK * b_ld;
+    f32x4 av[PV], bv[PV];
+    auto fetch = [&]() {
+#pragma unroll
+        for (int i = 0; i < PV; ++i) {
+            av[i] = (aok >> i) & 1 ? *reinterpret_cast<const f32x4*>(ap[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[i] = (bok >> i) & 1 ? *reinterpret_cast<const f32x4*>(bp[i]) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ap[i] += a_step;
+            bp[i] += b_step;
+        }
+    };
+    if (kz0 < kz1) fetch();
+    for (int k0 = kz0; k0 < kz1; k0 += TK) {
+        __syncthreads();  // the previous tile's fragments have been read
+#pragma unroll
+        for (int i = 0; i < PV; ++i) {
+            int r, k;
+            piece(AKC, i, r, k);
+            if (AKC) {
+                *reinterpret_cast<f32x4*>(&As[r][k]) = av[i];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) As[r + j][k] = av[i][j];
+            }
+            piece(BKC, i, r, k);
+            if (BKC) {
+                *reinterpret_cast<f32x4*>(&Bs[r][k]) = bv[i];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) Bs[r + j][k] = bv[i][j];
+            }
+        }
+        __syncthreads();
+        if (k0 + TK < kz1) fetch();
+        // fragment order as in gemm_f32_kernel: step (h, j) takes k = 8 fk + 4 h + j from the lane groups
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a[SUB], b[SUB];
+#pragma unroll
+            for (int i = 0; i < SUB; ++i) {
+                a[i] = *reinterpret_cast<const f32x4*>(&As[wm + 16 * i + fr][8 * fk + 4 * h]);
+                b[i] = *reinterpret_cast<const f32x4*>(&Bs[wn + 16 * i + fr][8 * fk + 4 * h]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < SUB; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < SUB; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][j], b[jj][j], acc[i][jj], 0, 0, 0);
+        }
+    }
+    if (slab_stride > 0) epi.C = reinterpret_cast<float*>(epi.C) + (long long)blockIdx.z * slab_stride;
+#pragma unroll
+    for (int i = 0; i < SUB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wm + i * 16 + 4 * fk + r;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < SUB; ++j) {
+                const int n = n0 + wn + j * 16 + fr;
+                if (n < N) epilogue_store<EPI, float, float>(epi, m, n, acc[i][j][r]);
+            }
+        }
+}
+
+// 0: not eligible; 1: k-contiguous; 2: row-contiguous
+inline int f32_fast_layout(const F32Operand& x) {
+    if (x.patch || (reinterpret_cast<uintptr_t>(x.p) & 15)) return 0;
+    if (x.s_k == 1 && x.s_r % 4 == 0) return 1;
+    if (x.s_r == 1 && x.s_k % 4 == 0 && x.R % 4 == 0) return 2;
+    return 0;
+}
+
+// Tile choice.  Below F32_SMALL_BELOW 64 x 64 tiles (four blocks per CU) a product runs on 32 x 32 tiles: a block's
+// K-loop is a chain of load latencies, and four times the blocks is four times the chains in flight (cfg 1 step:
+// 4.94 -> 4.49 ms).  From F32_BIG_FROM 128 x 128 tiles on (two blocks per CU) the 16-byte kernel runs on those: half
+// the LDS reads per product.
 constexpr long long F32_SMALL_BELOW = 1024;
+constexpr long long F32_BIG_FROM = 512;
+
+template <int EPI, int T>
+inline void launch_f32_tile(const F32Operand& a, const F32Operand& b, const Epilogue& epi, int M, int N, int K, int chunk,
+                            long long slab_stride, int splits, hipStream_t s) {
+    const dim3 grid(ceil_div(N, T), ceil_div(M, T), splits);
+    const int la = f32_fast_layout(a), lb = f32_fast_layout(b);
+    if (la && lb && K % 32 == 0 && chunk % 32 == 0 && !(la == 2 && lb == 1)) {
+        const long long ald = la == 1 ? a.s_r : a.s_k, bld = lb == 1 ? b.s_r : b.s_k;
+        if (la == 1 && lb == 1)
+            hipLaunchKernelGGL((gemm_f32_vec_kernel<EPI, T, true, true>), grid, dim3(256), 0, s, a.p, ald, a.R, b.p, bld, b.R, epi,
+                               M, N, K, chunk, slab_stride);
+        else if (la == 1)
+            hipLaunchKernelGGL((gemm_f32_vec_kernel<EPI, T, true, false>), grid, dim3(256), 0, s, a.p, ald, a.R, b.p, bld, b.R, epi,
+                               M, N, K, chunk, slab_stride);
+        else
+            hipLaunchKernelGGL((gemm_f32_vec_kernel<EPI, T, false, false>), grid, dim3(256), 0, s, a.p, ald, a.R, b.p, bld, b.R,
+                               epi, M, N, K, chunk, slab_stride);
+        return;
+    }
+    // the generic kernel needs the whole register file at 128 x 128: it stops at 64
+    constexpr int TG = T > 64 ? 64 : T;
+    hipLaunchKernelGGL((gemm_f32_kernel<EPI, TG>), dim3(ceil_div(N, TG), ceil_div(M, TG), splits), dim3(256), 0, s, a, b, epi, M,
+                       N, K, chunk, slab_stride, f32_vec_ok(a), f32_vec_ok(b));
+}
+
+template <int EPI>
+inline void launch_f32_pick(const F32Operand& a, const F32Operand& b, const Epilogue& epi, int M, int N, int K, int chunk,
+                            long long slab_stride, int splits, hipStream_t s) {
+    if ((long long)ceil_div(N, 128) * ceil_div(M, 128) * splits >= F32_BIG_FROM)
+        launch_f32_tile<EPI, 128>(a, b, epi, M, N, K, chunk, slab_stride, splits, s);
+    else if ((long long)ceil_div(N, 64) * ceil_div(M, 64) * splits < F32_SMALL_BELOW)
+        launch_f32_tile<EPI, 32>(a, b, epi, M, N, K, chunk, slab_stride, splits, s);
+    else
+        launch_f32_tile<EPI, 64>(a, b, epi, M, N, K, chunk, slab_stride, splits, s);
+}
 
 template <int EPI>
 inline void launch_f32_epi(const F32Operand& a, const F32Operand& b, const Epilogue& epi, int M, int N, int K, hipStream_t s) {
-    const dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
-    if ((long long)grid.x * grid.y < F32_SMALL_BELOW)
-        hipLaunchKernelGGL((gemm_f32_kernel<EPI, 32>), dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, s, a, b, epi, M, N,
-                           K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<EPI, 64>), grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a),
-                           f32_vec_ok(b));
+    launch_f32_pick<EPI>(a, b, epi, M, N, K, K, 0ll, 1, s);
 }
 
 // K chunks for an fp32 product whose output has few tiles (weight gradients): enough blocks for two per CU, chunks of
@@ -478,13 +635,8 @@ inline int launch_f32_plain(const F32Operand& a, const F32Operand& b, Epilogue e
         chunk = ((K + splits - 1) / splits + 31) / 32 * 32;
         splits = (K + chunk - 1) / chunk;
     }
-    dim3 grid(ceil_div(N, 64), ceil_div(M, 64), splits);
     if (splits <= 1) {
-        if ((long long)grid.x * grid.y < F32_SMALL_BELOW)
-            hipLaunchKernelGGL((gemm_f32_kernel<VITMI_EPI_NONE, 32>), dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, s, a, b,
-                               epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
-        else
-            hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, K, 0ll, f32_vec_ok(a), f32_vec_ok(b));
+        launch_f32_pick<VITMI_EPI_NONE>(a, b, epi, M, N, K, K, 0ll, 1, s);
         VITMI_LAUNCH_CHECK(what);
         return VITMI_OK;
     }
@@ -492,12 +644,7 @@ inline int launch_f32_plain(const F32Operand& a, const F32Operand& b, Epilogue e
     const long long ldc = epi.ldc;
     epi.C = slabs;
     epi.ldc = N;
-    if ((long long)grid.x * grid.y * grid.z < F32_SMALL_BELOW)
-        hipLaunchKernelGGL((gemm_f32_kernel<VITMI_EPI_NONE, 32>), dim3(ceil_div(N, 32), ceil_div(M, 32), splits), dim3(256), 0, s,
-                           a, b, epi, M, N, K, chunk, (long long)M * N, f32_vec_ok(a), f32_vec_ok(b));
-    else
-        hipLaunchKernelGGL(gemm_f32_kernel<VITMI_EPI_NONE>, grid, dim3(256), 0, s, a, b, epi, M, N, K, chunk, (long long)M * N,
-                           f32_vec_ok(a), f32_vec_ok(b));
+    launch_f32_pick<VITMI_EPI_NONE>(a, b, epi, M, N, K, chunk, (long long)M * N, splits, s);
     VITMI_LAUNCH_CHECK(what);
     const int blocks = (int)std::min<long long>(((long long)M * N + 255) / 256, 1024);
     hipLaunchKernelGGL(f32_slab_sum_kernel, dim3(blocks), dim3(256), 0, s, slabs, splits, M, N, out, ldc);
