@@ -14,6 +14,7 @@ timed region); `cpu_baseline` is the CPU oracle timed on the host cores on a bou
 `--workload` selects one of the reference's other configurations (same line format, each with
 `roofline` and `cpu_baseline`):
     vit_b16_224         ViT-B/16 224 px, batch 256 per GPU, bf16 (the default, the headline)
+    vit_b16_224_f32     the same geometry in the reference's own arithmetic: the library's exact fp32 mode
     cifar10_cpu         mymodel/ViT.py on the 32x32 / patch 4 geometry, batch 64, fp32: the reference's own
                         CPU-runnable case; the CPU oracle runs the whole batch-64 step beside the fp32 HIP path
     cifar100_export     the same geometry with 100 classes, bf16, batch 256: the training step, plus the forward
