@@ -119,6 +119,29 @@ long long vitmi_gemm_wgrad_workspace_bytes(int dt, int P, int Q, int T);
 int vitmi_gemm_wgrad(int dt, int P, int Q, int T, const void* U, long long ldu, const void* V, long long ldv,
                      float* C, long long ldc, void* workspace, void* stream);
 
+/* Many weight gradients over ONE token axis in one launch per 16 jobs: C_j[P_j][Q_j] (fp32) = U_j^T V_j, U_j [T, P_j]
+ * and V_j [T, Q_j] bf16 row-major with leading dimensions ldu, ldv (every `x.grad`-side product `dW = dy^T x` of the
+ * nn.Linear layers, mymodel/ViT.py:65-68,86,88, gathered after the backward pass instead of one small launch each
+ * beside it).  jobs is a HOST array.  Contract per job: the three pointers 16-byte aligned, P, Q, ldu, ldv multiples
+ * of 8, ldc a multiple of 4.  workspace: vitmi_gemm_wgrad_multi_workspace_bytes(jobs, n, T) bytes (fp32 partials of
+ * the token slabs, summed in slab order; NULL: one slab).  vitmi_ff_block_bwd / vitmi_attn_block_bwd called with
+ * both weight-gradient pointers NULL leave these products to the caller; their du / dqkv operands then sit at
+ * vitmi_ff_block_bwd_du_offset / vitmi_attn_block_bwd_dqkv_offset bytes into the workspace of that call. */
+typedef struct {
+    const void* U;
+    long long ldu;
+    const void* V;
+    long long ldv;
+    float* C;
+    long long ldc;
+    int P;
+    int Q;
+} vitmi_wgrad_job;
+long long vitmi_gemm_wgrad_multi_workspace_bytes(const vitmi_wgrad_job* jobs, int n, long long T);
+int vitmi_gemm_wgrad_multi(const vitmi_wgrad_job* jobs, int n, long long T, void* workspace, void* stream);
+long long vitmi_ff_block_bwd_du_offset(int dt, int rows, int D, int M);
+long long vitmi_attn_block_bwd_dqkv_offset(int dt, int B, int N, int D, int H, int DH);
+
 /* Two weight gradients over the SAME T tokens, C0 [P0,Q0] = U0^T V0 and C1 [P1,Q1] = U1^T V1 (both dense fp32):
  * the two nn.Linear weight gradients of one pre-norm sub-block (mymodel/ViT.py:66,69 resp. :86,89), which autograd
  * computes as two GEMMs.  In bf16 with every extent a multiple of 256 and T a multiple of 64 both run in ONE launch
@@ -374,8 +397,9 @@ int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const voi
 /* At the small geometry (bf16, D <= 256 and a multiple of 32, hidden width a multiple of 32, 16-byte aligned
  * operands) the block calls run as one-launch kernels that keep the sub-block's activations in LDS; same outputs to the
  * bf16 bar.  vitmi_debug_set_small_fused(mask): bit 0 = the MLP sub-block's forward, bit 1 = the attention
- * sub-block's forward (up to 96 tokens, heads of 8 or 16, no probability export), bit 2 = the MLP sub-block's backward
- * (default 3: the two forward kernels; a negative mask restores the default);
+ * sub-block's forward (up to 96 tokens, heads of 8 or 16, no probability export), bit 2 = the MLP sub-block's backward,
+ * bit 3 = that backward kernel in calls that leave the weight gradients to the caller (dw1 == dw2 == NULL)
+ * (default 11: the two forward kernels and bit 3; a negative mask restores the default);
  * process-wide, for benchmarking and for the tests that compare the two forms. */
 int vitmi_debug_set_small_fused(int mask);
 /* The two weight-gradient products of a sub-block's backward call may run on a second stream of the library's own,

@@ -209,3 +209,97 @@ def test_ff_block_backward_one_launch_against_steps_and_fp64(rows, D, M, erf):
     ref = dict(dx=x.grad, dgamma=gamma.grad, dbeta=beta.grad, dw1=w1.grad, db1=b1.grad, dw2=w2.grad, db2=b2.grad)
     for k, v in ref.items():
         assert rel_err(fused[k].double(), v) < 2e-2, k
+
+
+def test_wgrad_multi_against_single_products():
+    """vitmi_gemm_wgrad_multi: 20 jobs over one token axis (two launches of up to 16), ragged 128 x 128 tiles, with the
+    slab workspace and without it, against the fp32 products of the bf16 operands and the one-product entry point."""
+    import ctypes
+    from visiontransformer_amd import ops
+    from visiontransformer_amd._lib import check, lib
+    T = 16640
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(288, 192), (192, 96), (512, 192), (192, 512), (8, 8), (136, 264)]
+    us, vs, outs, refs = [], [], [], []
+    for k in range(20):
+        P, Q = shapes[k % len(shapes)]
+        us.append(torch.randn(T, P, generator=gen).to(DEV).bfloat16())
+        vs.append(torch.randn(T, Q, generator=gen).to(DEV).bfloat16())
+        refs.append(us[-1].float().t() @ vs[-1].float())
+    for with_ws in (True, False):
+        outs = [torch.full((u.shape[1], v.shape[1]), float("nan"), device=DEV) for u, v in zip(us, vs)]
+        jobs = (ops._WgradJob * 20)()
+        for j, u, v, c in zip(jobs, us, vs, outs):
+            j.U, j.ldu, j.V, j.ldv, j.C, j.ldc, j.P, j.Q = u.data_ptr(), u.shape[1], v.data_ptr(), v.shape[1], c.data_ptr(), \
+                c.shape[1], u.shape[1], v.shape[1]
+        ws = None
+        if with_ws:
+            nbytes = lib.vitmi_gemm_wgrad_multi_workspace_bytes(ctypes.addressof(jobs), 20, T)
+            assert nbytes > 0
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        check(lib.vitmi_gemm_wgrad_multi(ctypes.addressof(jobs), 20, T, None if ws is None else ws.data_ptr(),
+                                         torch.cuda.current_stream().cuda_stream), "vitmi_gemm_wgrad_multi")
+        for u, v, c, r in zip(us, vs, outs, refs):
+            assert rel_err(c, r) < 1e-5
+            if u.shape[1] % 8 == 0:
+                assert rel_err(c, ops.linear_bwd_w(u, v)) < 1e-5
+
+
+def test_deferred_weight_gradients_match_immediate_ones():
+    """The weight gradients of the small geometry gathered after the backward pass (one vitmi_gemm_wgrad_multi call
+    from an autograd-engine callback) against the ones each sub-block launches itself: same values to summation order;
+    the queue is not used when a parameter already holds a gradient (accumulation) or carries a hook, and
+    torch.autograd.grad gets filled tensors as well."""
+    from visiontransformer_amd import ViT, ops
+    from visiontransformer_amd._lib import lib
+    kw = dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=3, heads=12, mlp_dim=512, dim_head=8)
+    torch.manual_seed(0)
+    m = ViT.VIT(**kw).to(DEV).set_compute_dtype(torch.bfloat16).train()
+    x = torch.randn(32, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (32,), device=DEV)
+
+    def grads(defer, accumulate=False):
+        ops.set_defer_wgrad(defer)
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p) if accumulate else None
+        before = dict(ops.deferred_stats)
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}, ops.deferred_stats["jobs"] - before["jobs"]
+
+    try:
+        # with the deferred products the MLP sub-block's backward is one launch by default (nothing runs beside it);
+        # that form against the launch-per-step one is a bf16-bar comparison ...
+        ref, n0 = grads(False)
+        got, n1 = grads(True)
+        assert n0 == 0 and n1 == 4 * kw["depth"]
+        for k in ref:
+            assert rel_err(got[k], ref[k]) < 2e-2, k
+        # ... and with the same sub-block kernels on both sides only the summation order of the products differs
+        lib.vitmi_debug_set_small_fused(3)
+        ref, n0 = grads(False)
+        got, n1 = grads(True)
+        assert n0 == 0 and n1 == 4 * kw["depth"]
+        for k in ref:
+            assert rel_err(got[k], ref[k]) < 1e-5, k
+        acc, n2 = grads(True, accumulate=True)          # .grad present: the sub-blocks launch their own products
+        assert n2 == 0
+        for k in ref:
+            assert rel_err(acc[k], ref[k]) < 1e-5, k
+        w = dict(m.named_parameters())["transformer.layers.0.1.fn.net.0.weight"]
+        params = [p for p in m.parameters()]
+        for p in params:
+            p.grad = None
+        ops.set_defer_wgrad(True)
+        gs = torch.autograd.grad(torch.nn.functional.cross_entropy(m(x), y), params)
+        for (k, _), g in zip(m.named_parameters(), gs):
+            assert rel_err(g, ref[k]) < 1e-5, k
+        h = w.register_hook(lambda g: g)                # a tensor hook on one weight: its sub-block does not defer
+        hooked, n3 = grads(True)
+        h.remove()
+        assert n3 == 4 * kw["depth"] - 2
+        for k in ref:
+            assert rel_err(hooked[k], ref[k]) < 1e-5, k
+    finally:
+        ops.set_defer_wgrad(True)
+        lib.vitmi_debug_set_small_fused(-1)

@@ -69,6 +69,21 @@ assert lib.vitmi_colsum_workspace_bytes(2 ** 40, 4096) > 0
 assert lib.vitmi_layernorm_bwd_workspace_bytes(2 ** 40, 1024) > 0
 assert lib.vitmi_rollout_workspace_bytes(12, 256, 197) > 0
 assert lib.vitmi_tokens_assemble_bwd_workspace_bytes(197, 768) > 0
+# the multi-job weight gradient: size query over a host job table (chunks of 16), misaligned job rejected
+import ctypes
+from visiontransformer_amd.ops import _WgradJob
+jobs = (_WgradJob * 20)()
+for j in jobs:
+    j.U, j.ldu, j.V, j.ldv, j.C, j.ldc, j.P, j.Q = 4096, 512, 8192, 192, 16384, 192, 512, 192
+assert lib.vitmi_gemm_wgrad_multi_workspace_bytes(ctypes.addressof(jobs), 20, 16640) > 0
+assert lib.vitmi_gemm_wgrad_multi_workspace_bytes(ctypes.addressof(jobs), 20, big) > 0
+assert lib.vitmi_gemm_wgrad_multi_workspace_bytes(None, 20, 16640) == 0
+jobs[3].P = 100
+assert lib.vitmi_gemm_wgrad_multi(ctypes.addressof(jobs), 20, 16640, None, None) != 0 and b"job 3" in lib.vitmi_last_error()
+assert lib.vitmi_gemm_wgrad_multi(None, 0, 16640, None, None) == 0
+assert lib.vitmi_ff_block_bwd_du_offset(_lib.BF16, 16640, 192, 512) == 0
+assert lib.vitmi_attn_block_bwd_dqkv_offset(_lib.BF16, 256, 65, 192, 12, 8) == 256 * 65 * 96 * 2
+assert lib.vitmi_adam_step_matrices(None, None, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) != 0
 # argument checks: a clean error code and a message, never a crash
 assert lib.vitmi_attn_fwd(None, None, None, None, _lib.BF16, 1, 1, 1, 64, 0, None) != 0 and lib.vitmi_last_error()
 assert lib.vitmi_attn_bwd(None, None, None, None, None, None, None, _lib.BF16, 1, 1, 1, 64, 0, None) != 0

@@ -119,6 +119,10 @@ SIGNATURES = {
     "vitmi_adam_step": (I, [P, P, P, P, P, L, F, F, F, F, F, I, F, P]),
     "vitmi_adam_step_multi": (I, [P, I, P, I, I, F, F, F, F, F, I, F, P]),
     "vitmi_adam_step_matrices": (I, [P, P, I, L, F, F, F, F, F, I, F, P]),
+    "vitmi_gemm_wgrad_multi_workspace_bytes": (L, [P, I, L]),
+    "vitmi_gemm_wgrad_multi": (I, [P, I, L, P, P]),
+    "vitmi_ff_block_bwd_du_offset": (L, [I, I, I, I]),
+    "vitmi_attn_block_bwd_dqkv_offset": (L, [I, I, I, I, I, I]),
 }
 
 

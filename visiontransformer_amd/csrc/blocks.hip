@@ -112,7 +112,7 @@ extern "C" int vitmi_debug_set_wgrad_overlap(int mode) {
 // the sub-block as ONE launch at the small geometry (small.hip); NOT_TAKEN = operands not 16-byte aligned, nothing enqueued
 enum { VITMI_SMALL_NOT_TAKEN = 1000 };
 bool vitmi_ff_small_ok(int dt, long long rows, int D, int M);
-bool vitmi_ff_small_bwd_ok(int dt, long long rows, int D, int M);
+bool vitmi_ff_small_bwd_ok(int dt, long long rows, int D, int M, bool caller_forms_dw);
 long long vitmi_ff_small_bwd_partial_bytes(long long rows, int D, int M);
 int vitmi_ff_small_bwd(long long rows, int D, int M, const void* dy, const void* x, const void* u, const float* gamma,
                        const float* mean, const float* rstd, const void* w2_t, const void* w1_t, void* du, void* dx,
@@ -162,13 +162,18 @@ extern "C" long long vitmi_ff_block_bwd_workspace_bytes(int dt, int rows, int D,
            ff_chain_scratch(rows, D, M) + align256(vitmi_gemm_wgrad_pair_workspace_bytes(dt, rows, D, M, M, D));
 }
 
+extern "C" long long vitmi_ff_block_bwd_du_offset(int dt, int rows, int D, int M) {
+    (void)dt; (void)rows; (void)D; (void)M;
+    return 0;   // du [rows, M] opens the workspace
+}
+
 extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const void* x, const void* xn,
                                   const void* u, const void* h, const float* gamma, const float* mean, const float* rstd,
                                   const void* w1, const void* w1_t, const void* w2, const void* w2_t, void* dx,
                                   float* dgamma, float* dbeta, float* dw1, float* db1, float* dw2, float* db2,
                                   void* workspace, void* stream) {
-    VITMI_CHECK_ARG(dy && x && xn && u && h && gamma && mean && rstd && w1 && w2 && dx && dgamma && dbeta && dw1 && db1 &&
-                        dw2 && db2 && workspace,
+    VITMI_CHECK_ARG(dy && x && xn && u && h && gamma && mean && rstd && w1 && w2 && dx && dgamma && dbeta && db1 && db2 &&
+                        workspace && ((dw1 != nullptr) == (dw2 != nullptr)),
                     "vitmi_ff_block_bwd: null pointer");
     VITMI_CHECK_ARG(rows > 0 && D > 0 && M > 0, "vitmi_ff_block_bwd: bad shape rows=%d D=%d M=%d", rows, D, M);
     char* ws = (char*)workspace;
@@ -176,19 +181,24 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
     void* dxn = ws + align256((long long)rows * M * esize(dt));
     void* scratch = (char*)dxn + align256((long long)rows * D * esize(dt));
     void* wg_scratch = (char*)scratch + ff_chain_scratch(rows, D, M);
-    Side* sd = overlap_side(rows, D, stream);
+    // dw1 == dw2 == null: the caller forms the weight gradients itself, later (vitmi_gemm_wgrad_multi), from dy, h, xn
+    // and du, which it finds at vitmi_ff_block_bwd_du_offset in the workspace it keeps until then
+    const bool skip_w = !dw1;
+    Side* sd = skip_w ? nullptr : overlap_side(rows, D, stream);
     if (sd) {
         STEP(side_fork(sd, stream));
         STEP(vitmi_gemm_wgrad(dt, D, M, rows, dy, D, h, M, dw2, M, wg_scratch, sd->s));
     }
-    if (w1_t && w2_t && vitmi_ff_small_bwd_ok(dt, rows, D, M)) {
+    if (w1_t && w2_t && vitmi_ff_small_bwd_ok(dt, rows, D, M, skip_w)) {
         // one launch for du, dxn and the LayerNorm backward (small.hip); the sums for db1, dgamma, dbeta, db2 are
         // finished by a small kernel that, like the weight gradients, need not sit on the caller's chain
         const int rc = vitmi_ff_small_bwd(rows, D, M, dy, x, u, gamma, mean, rstd, w2_t, w1_t, du, dx, (float*)scratch,
                                           g_classic_gelu_pair, stream);
         if (rc != VITMI_SMALL_NOT_TAKEN) {
             if (rc != VITMI_OK) return rc;
-            if (sd) {
+            if (skip_w) {
+                STEP(vitmi_ff_small_bwd_final(rows, D, M, (const float*)scratch, db1, dgamma, dbeta, db2, stream));
+            } else if (sd) {
                 STEP(side_fork(sd, stream, true));
                 STEP(vitmi_gemm_wgrad(dt, M, D, rows, du, M, xn, D, dw1, D, wg_scratch, sd->s));
                 STEP(vitmi_ff_small_bwd_final(rows, D, M, (const float*)scratch, db1, dgamma, dbeta, db2, sd->s));
@@ -205,7 +215,7 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
     if (sd) {
         STEP(side_fork(sd, stream, true));
         STEP(vitmi_gemm_wgrad(dt, M, D, rows, du, M, xn, D, dw1, D, wg_scratch, sd->s));
-    } else {
+    } else if (!skip_w) {
         // both weight gradients of the sub-block share the token axis: one launch where the shapes allow it
         STEP(vitmi_gemm_wgrad_pair(dt, rows, D, M, dy, D, h, M, dw2, M, D, du, M, xn, D, dw1, wg_scratch, stream));
     }
@@ -289,6 +299,11 @@ extern "C" long long vitmi_attn_block_bwd_workspace_bytes(int dt, int B, int N, 
            align256(vitmi_gemm_wgrad_pair_workspace_bytes(dt, rows, D, I, 3 * I, D));
 }
 
+extern "C" long long vitmi_attn_block_bwd_dqkv_offset(int dt, int B, int N, int D, int H, int DH) {
+    (void)D;
+    return align256((long long)B * N * H * DH * esize(dt));   // behind dout [rows, H * DH]
+}
+
 extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, const void* dy, const void* x,
                                     const void* xn, const void* qkv, const void* o, const float* lse, const float* gamma,
                                     const float* mean, const float* rstd, const void* w_qkv, const void* w_qkv_t,
@@ -296,7 +311,7 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
                                     float* dw_qkv, float* db_qkv, float* dw_out, float* db_out, void* workspace,
                                     int qkv_layout, void* stream) {
     VITMI_CHECK_ARG(dy && x && xn && qkv && o && lse && gamma && mean && rstd && w_qkv && w_out && dx && dgamma && dbeta &&
-                        dw_qkv && dw_out && workspace,
+                        workspace && ((dw_qkv != nullptr) == (dw_out != nullptr)),
                     "vitmi_attn_block_bwd: null pointer");
     VITMI_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && DH > 0, "vitmi_attn_block_bwd: bad shape");
     VITMI_CHECK_ARG(qkv_layout == 0 || qkv_layout == VITMI_QKV_HEAD_MAJOR, "vitmi_attn_block_bwd: bad qkv layout %d", qkv_layout);
@@ -309,8 +324,12 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
     void* wg_scratch = (char*)scratch + attn_chain_scratch(dt, B, N, D, H, DH);
     // dqkv lives in the workspace, so its layout is this call's own choice: planes when the three consumers below can
     // read them (a qkv bias wants the column sums of the row-major matrix; the input gradient wants the transposed weight)
-    const bool dq_planes = (g_qkv_planes & 2) && !db_qkv && w_qkv_t && vitmi_qkv_planes_ok(dt, B, N, D, H, DH, xn, w_qkv_t, dqkv);
-    Side* sd = dq_planes ? nullptr : overlap_side(rows, D, stream);  // (planes: heads of 64, never a small shape)
+    // dw_qkv == dw_out == null: the weight gradients are the caller's, later (vitmi_gemm_wgrad_multi), from dy, o, xn
+    // and dqkv, which stays row-major at vitmi_attn_block_bwd_dqkv_offset in the workspace the caller keeps until then
+    const bool skip_w = !dw_qkv;
+    const bool dq_planes = !skip_w && (g_qkv_planes & 2) && !db_qkv && w_qkv_t &&
+                           vitmi_qkv_planes_ok(dt, B, N, D, H, DH, xn, w_qkv_t, dqkv);
+    Side* sd = (dq_planes || skip_w) ? nullptr : overlap_side(rows, D, stream);  // (planes: heads of 64, never a small shape)
     if (sd) {
         STEP(side_fork(sd, stream));
         STEP(vitmi_gemm_wgrad(dt, D, I, rows, dy, D, o, I, dw_out, I, wg_scratch, sd->s));
@@ -325,7 +344,7 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
         if (sd) {
             STEP(side_fork(sd, stream, true));
             STEP(vitmi_gemm_wgrad(dt, 3 * I, D, rows, dqkv, 3 * I, xn, D, dw_qkv, D, wg_scratch, sd->s));
-        } else {
+        } else if (!skip_w) {
             STEP(vitmi_gemm_wgrad_pair(dt, rows, D, I, dy, D, o, I, dw_out, 3 * I, D, dqkv, 3 * I, xn, D, dw_qkv, wg_scratch,
                                        stream));
         }

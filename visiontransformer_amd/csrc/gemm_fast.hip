@@ -956,6 +956,122 @@ __global__ __launch_bounds__(64 * WP * WQ) void gemm_tn_fast_kernel(const bf16_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// Many weight gradients over one token axis in ONE launch: job j is C_j[P_j][Q_j] = U_j^T V_j over the same T tokens
+// (the weight gradients of several sub-blocks, formed after the backward pass instead of one small launch each
+// beside it).  The grid is slabs x (the 128 x 128 tiles of all jobs); a block finds its job from the tile prefix,
+// runs the two-stage loop of gemm_tn_fast_kernel over its slab of token tiles and writes a dense [P_j][Q_j] fp32
+// partial (or C_j itself with one slab); tn_multi_reduce_kernel adds the slabs in index order.
+// ------------------------------------------------------------------------------------------------
+constexpr int TNM_MAX = 16;
+struct TnMulti {
+    const bf16_t* U[TNM_MAX];
+    const bf16_t* V[TNM_MAX];
+    float* C[TNM_MAX];
+    long long slab_off[TNM_MAX];   // first float of job j's [ns][P][Q] partials inside `slabs`
+    int ldu[TNM_MAX], ldv[TNM_MAX], ldc[TNM_MAX], P[TNM_MAX], Q[TNM_MAX], tiles_q[TNM_MAX];
+    int tile_begin[TNM_MAX + 1];
+    float* slabs;
+    int njobs, T, ns, per;         // per: token tiles per slab
+};
+
+__global__ __launch_bounds__(256) void gemm_tn_multi_kernel(const TnMulti tm) {
+    constexpr int BP = 128, BQ = 128, WP = 2, WQ = 2, NW = 4, WTP = 64, WTQ = 64, MI = 4, NJ = 4;
+    constexpr int STAGE = TK * (BP + BQ);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+    const int tiles = tm.tile_begin[tm.njobs];
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int slab = lin / tiles;
+    int tile = lin - slab * tiles;
+    int job = 0;
+#pragma unroll
+    for (int k = 1; k < TNM_MAX; ++k)
+        if (k < tm.njobs && tile >= tm.tile_begin[k]) job = k;
+    tile -= tm.tile_begin[job];
+    const bf16_t* __restrict__ U = tm.U[job];
+    const bf16_t* __restrict__ V = tm.V[job];
+    const long long ldu = tm.ldu[job], ldv = tm.ldv[job];
+    const int P = tm.P[job], Q = tm.Q[job], tq = tm.tiles_q[job], T = tm.T;
+    const int p0 = (tile / tq) * BP, q0 = (tile % tq) * BQ;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wp = wave / WQ, wq = wave % WQ;
+    const int fr = lane & 15, fg = lane >> 4;
+    f32x4 acc[NJ][MI];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nk_all = (T + TK - 1) / TK;
+    const int kt_begin = slab * tm.per, kt_end = min(kt_begin + tm.per, nk_all);
+    if (kt_begin < kt_end) {
+        stage_tn<BP, NW>(U, ldu, kt_begin * TK, T, p0, P, smem, wave, lane);
+        stage_tn<BQ, NW>(V, ldv, kt_begin * TK, T, q0, Q, smem + TK * BP, wave, lane);
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int b = (kt - kt_begin) & 1;
+        bf16_t* Us = smem + b * STAGE;
+        bf16_t* Vs = Us + TK * BP;
+        if (kt + 1 < kt_end) {
+            bf16_t* Un = smem + (b ^ 1) * STAGE;
+            stage_tn<BP, NW>(U, ldu, (kt + 1) * TK, T, p0, P, Un, wave, lane);
+            stage_tn<BQ, NW>(V, ldv, (kt + 1) * TK, T, q0, Q, Un + TK * BP, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < TK / 32; ++ks) {
+            bf16x8 fv[NJ], fu[MI];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fv[j] = frag_tn<BQ>(Vs, wq * WTQ + j * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fu[i] = frag_tn<BP>(Us, wp * WTP + i * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[j], fu[i], acc[j][i], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // acc[j][i][r] = C[p = p0 + wp*WTP + i*16 + fr][q = q0 + wq*WTQ + j*16 + 4*fg + r]
+    float* out;
+    long long ldo;
+    if (tm.ns > 1) {
+        out = tm.slabs + tm.slab_off[job] + (long long)slab * P * Q;
+        ldo = Q;
+    } else {
+        out = tm.C[job];
+        ldo = tm.ldc[job];
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int p = p0 + wp * WTP + i * 16 + fr;
+        if (p >= P) continue;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = q0 + wq * WTQ + j * 16 + 4 * fg;
+            if (q + 4 <= Q) *reinterpret_cast<f32x4*>(out + (long long)p * ldo + q) = acc[j][i];   // Q % 8 == 0
+        }
+    }
+}
+
+// C_j[p][q] = sum over slabs of job j's partials, in slab order; grid (blocks, jobs)
+__global__ void tn_multi_reduce_kernel(const TnMulti tm) {
+    const int job = blockIdx.y;
+    const int P = tm.P[job], Q = tm.Q[job];
+    const long long n4 = (long long)P * Q / 4, pq = (long long)P * Q;
+    const float* __restrict__ src = tm.slabs + tm.slab_off[job];
+    float* __restrict__ C = tm.C[job];
+    const long long ldc = tm.ldc[job];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        for (int k = 1; k < tm.ns; ++k) s += *reinterpret_cast<const f32x4*>(src + k * pq + 4 * i);
+        const long long e = 4 * i, p = e / Q, q = e - p * Q;
+        *reinterpret_cast<f32x4*>(C + p * ldc + q) = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // tn kernel, phased variant (T % 64 == 0): the schedule of gemm_nt_phased_kernel (four phases of 16
 // MFMAs per 64-deep token tile, two wave groups one barrier apart, regions streamed six ahead
 // with a counted vmcnt) on [64 t][128 cols] regions read through ds_read_b64_tr_b16:
@@ -1820,6 +1936,104 @@ static int launch_tn_fast(int P, int Q, int T, const void* U, long long ldu, con
     if (pick_tn_cfg(P, Q) >= 1)
         return launch_tn_cfg<PATCH, 256, 256, 2, 4>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s, u_plane);
     return launch_tn_cfg<PATCH, 128, 128, 2, 2>(P, Q, T, U, ldu, V, ldv, C, ldc, slabs, ns, pg, s, u_plane);
+}
+
+// ---- vitmi_gemm_wgrad_multi: jobs over one token axis, TNM_MAX per launch
+static int tn_multi_slabs(int tiles, int T) {
+    const int nk = ceil_div(T, TK);
+    int ns = 2 * phased_grid_blocks() / (tiles > 0 ? tiles : 1);   // two 64-KiB blocks fit a CU
+    if (ns > nk) ns = nk;
+    if (ns > 32) ns = 32;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+static int tn_multi_slabs_bound(int tiles, int T) {
+    const int nk = ceil_div(T, TK);
+    int ns = 2 * full_grid_blocks() / (tiles > 0 ? tiles : 1);
+    if (ns > nk) ns = nk;
+    if (ns > 32) ns = 32;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+static bool tn_multi_job_ok(const vitmi_wgrad_job& j) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return j.U && j.V && j.C && al(j.U) && al(j.V) && al(j.C) && j.P > 0 && j.Q > 0 && j.P % 8 == 0 && j.Q % 8 == 0 &&
+           j.ldu >= j.P && j.ldv >= j.Q && j.ldu % 8 == 0 && j.ldv % 8 == 0 && j.ldc >= j.Q && j.ldc % 4 == 0 &&
+           j.ldu < (1ll << 31) && j.ldv < (1ll << 31) && j.ldc < (1ll << 31);
+}
+
+extern "C" long long vitmi_gemm_wgrad_multi_workspace_bytes(const vitmi_wgrad_job* jobs, int n, long long T) {
+    if (!jobs || n <= 0 || T <= 0 || T >= (1ll << 31)) return 0;
+    long long worst = 0;
+    for (int b = 0; b < n; b += TNM_MAX) {
+        const int m = n - b < TNM_MAX ? n - b : TNM_MAX;
+        int tiles = 0;
+        long long elems = 0;
+        for (int k = 0; k < m; ++k) {
+            tiles += ceil_div(jobs[b + k].P, 128) * ceil_div(jobs[b + k].Q, 128);
+            elems += (long long)jobs[b + k].P * jobs[b + k].Q;
+        }
+        const long long bytes = (long long)tn_multi_slabs_bound(tiles, (int)T) * elems * (long long)sizeof(float);
+        if (bytes > worst) worst = bytes;
+    }
+    return worst;
+}
+
+extern "C" int vitmi_gemm_wgrad_multi(const vitmi_wgrad_job* jobs, int n, long long T, void* workspace, void* stream) {
+    VITMI_CHECK_ARG(n >= 0 && T > 0 && T < (1ll << 31), "vitmi_gemm_wgrad_multi: bad argument");
+    if (n == 0) return VITMI_OK;
+    VITMI_CHECK_ARG(jobs, "vitmi_gemm_wgrad_multi: null job table");
+    for (int k = 0; k < n; ++k)
+        VITMI_CHECK_ARG(tn_multi_job_ok(jobs[k]),
+                        "vitmi_gemm_wgrad_multi: job %d: bf16 operands and the fp32 result 16-byte aligned, P, Q and the "
+                        "leading dimensions multiples of 8 (ldc of 4)", k);
+    hipStream_t s = as_stream(stream);
+    static unsigned long long done = 0;
+    constexpr size_t lds = 2 * (size_t)TK * 256 * sizeof(bf16_t);
+    int rc = ensure_lds_attr(reinterpret_cast<const void*>(gemm_tn_multi_kernel), lds, &done);
+    if (rc != VITMI_OK) return rc;
+    for (int b = 0; b < n; b += TNM_MAX) {
+        TnMulti tm{};
+        tm.njobs = n - b < TNM_MAX ? n - b : TNM_MAX;
+        tm.T = (int)T;
+        long long elems = 0;
+        double flops = 0;
+        int tiles = 0;
+        for (int k = 0; k < tm.njobs; ++k) {
+            const vitmi_wgrad_job& j = jobs[b + k];
+            tm.U[k] = (const bf16_t*)j.U;
+            tm.V[k] = (const bf16_t*)j.V;
+            tm.C[k] = j.C;
+            tm.ldu[k] = (int)j.ldu;
+            tm.ldv[k] = (int)j.ldv;
+            tm.ldc[k] = (int)j.ldc;
+            tm.P[k] = j.P;
+            tm.Q[k] = j.Q;
+            tm.tiles_q[k] = ceil_div(j.Q, 128);
+            tm.tile_begin[k] = tiles;
+            tm.slab_off[k] = elems;     // scaled by the slab count below
+            tiles += ceil_div(j.P, 128) * tm.tiles_q[k];
+            elems += (long long)j.P * j.Q;
+            flops += 2.0 * j.P * j.Q * (double)T;
+        }
+        for (int k = tm.njobs; k <= TNM_MAX; ++k) tm.tile_begin[k] = tiles;
+        tm.tile_begin[tm.njobs] = tiles;
+        const int nk = ceil_div((int)T, TK);
+        int ns = workspace ? tn_multi_slabs(tiles, (int)T) : 1;
+        tm.per = ceil_div(nk, ns);
+        ns = ceil_div(nk, tm.per);
+        tm.ns = ns;
+        for (int k = 0; k < tm.njobs; ++k) tm.slab_off[k] *= ns;
+        tm.slabs = (float*)workspace;
+        ProfScope prof(VITMI_FAM_GEMM_TN_FAST, s, flops);
+        hipLaunchKernelGGL(gemm_tn_multi_kernel, dim3(tiles * ns), dim3(256), lds, s, tm);
+        VITMI_LAUNCH_CHECK("vitmi_gemm_wgrad_multi");
+        if (ns > 1) {
+            hipLaunchKernelGGL(tn_multi_reduce_kernel, dim3(64, tm.njobs), dim3(256), 0, s, tm);
+            VITMI_LAUNCH_CHECK("vitmi_gemm_wgrad_multi(reduce)");
+        }
+    }
+    return VITMI_OK;
 }
 
 // per-segment tile sums of squares: partial[seg][tile]; returns the number of tiles per segment through *tiles

@@ -385,7 +385,7 @@ int launch_ff_small(const FfSmallArgs& a, hipStream_t s) {
 // (the backward kernel is opt-in: beside the weight gradients on the second stream it is no faster than the four
 // launches it replaces -- 3.29 -> 3.46 ms per step at the 32-pixel geometry, batch 256, graph replay; it saves host time
 // when the step is issued eagerly: 4.57 -> 4.45 ms)
-constexpr int SMALL_DEFAULT = 3;
+constexpr int SMALL_DEFAULT = 3 | 8;
 template <int MT>
 int launch_ff_small_bwd(const FfSmallBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)MT * 16 * ((a.D + SM_PAD) + (a.M + SM_PAD)) * sizeof(bf16_t) + (size_t)2 * SM_WAVES * MT * 16 * sizeof(float);
@@ -415,7 +415,9 @@ int ff_small_bwd_tiles(long long rows, int D, int M) {
     return best;
 }
 
-int g_small_fused = SMALL_DEFAULT;  // bit 0: MLP sub-block forward, bit 1: attention sub-block forward, bit 2: MLP sub-block backward
+// bit 0: MLP sub-block forward, bit 1: attention sub-block forward, bit 2: MLP sub-block backward, bit 3: the same
+// backward kernel in calls that leave the weight gradients to the caller (nothing then runs beside it)
+int g_small_fused = SMALL_DEFAULT;
 
 }  // namespace
 
@@ -459,8 +461,8 @@ int vitmi_ff_small_fwd(long long rows, int D, int M, const void* x, const float*
 }
 
 // ---- MLP sub-block backward
-bool vitmi_ff_small_bwd_ok(int dt, long long rows, int D, int M) {
-    if (!(g_small_fused & 4) || dt != VITMI_BF16 || rows <= 0) return false;
+bool vitmi_ff_small_bwd_ok(int dt, long long rows, int D, int M, bool caller_forms_dw) {
+    if (!(g_small_fused & (caller_forms_dw ? 12 : 4)) || dt != VITMI_BF16 || rows <= 0) return false;
     if (D < 32 || D > 256 || D % 32 != 0 || M < 32 || M % 32 != 0) return false;
     return (size_t)2 * 16 * ((D + SM_PAD) + (M + SM_PAD)) * sizeof(bf16_t) + (size_t)2 * SM_WAVES * 32 * sizeof(float) <= 160 * 1024;
 }

@@ -981,6 +981,83 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+# ---------------------------------------------------------------------------------------------
+# weight gradients of the small geometry, gathered after the backward pass
+# ---------------------------------------------------------------------------------------------
+# At widths where a sub-block's products are a few microseconds each (the 32-pixel models), its two weight-gradient
+# products are not launched by the sub-block's backward call: they are queued, and one vitmi_gemm_wgrad_multi call at
+# the end of the autograd pass (an engine callback) forms all of them, 16 products per launch.  The gradient tensors
+# handed to autograd in between are allocated but not yet filled, so the queue is used only when nothing reads them
+# before the pass ends: the parameter has no gradient to accumulate into and no hooks (a GradReducer's buckets, a
+# tensor hook).  VITMI_DEFER_WGRAD=0 or set_defer_wgrad(False) switches it off.
+import ctypes as _ct
+
+
+class _WgradJob(_ct.Structure):
+    _fields_ = [("U", _ct.c_void_p), ("ldu", _ct.c_longlong), ("V", _ct.c_void_p), ("ldv", _ct.c_longlong),
+                ("C", _ct.c_void_p), ("ldc", _ct.c_longlong), ("P", _ct.c_int), ("Q", _ct.c_int)]
+
+
+_defer_wgrad = os.environ.get("VITMI_DEFER_WGRAD", "1") != "0"
+_deferred = {"task": None, "groups": {}, "keep": []}
+deferred_stats = {"jobs": 0, "flushes": 0}     # running totals, for tests and diagnostics
+_graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
+
+
+def set_defer_wgrad(on):
+    global _defer_wgrad
+    _defer_wgrad = bool(on)
+
+
+def _defer_ok(cdt, rows, D, params):
+    if not _defer_wgrad or cdt != torch.bfloat16 or rows * D > (8 << 20) or _graph_task_id is None:
+        return False
+    if _graph_task_id() < 0:
+        return False
+    for p in params:
+        if (not p.is_leaf or p.grad is not None or p._backward_hooks
+                or getattr(p, "_post_accumulate_grad_hooks", None)):
+            return False
+    return True
+
+
+def _defer_jobs(rows, device, jobs, keep):
+    """jobs: (U ptr, ldu, V ptr, ldv, C ptr, P, Q, parameter) over `rows` tokens; keep: tensors the operands live in.
+    The result tensor itself is NOT kept: a second reference would make autograd's AccumulateGrad copy it (still
+    empty) instead of adopting it as the parameter's .grad."""
+    task = _graph_task_id()
+    st = _deferred
+    if st["task"] != task:
+        # a pass that ended without its callback (an exception) leaves jobs that will never be wanted
+        st["task"], st["groups"], st["keep"] = task, {}, []
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+    st["groups"].setdefault((device, rows, _stream()), []).extend(jobs)
+    deferred_stats["jobs"] += len(jobs)
+    st["keep"].extend(keep)
+
+
+def _flush_deferred():
+    st = _deferred
+    groups, st["groups"], keep, st["keep"], st["task"] = st["groups"], {}, st["keep"], [], None
+    deferred_stats["flushes"] += 1
+    for (device, rows, stream), jobs in groups.items():
+        arr = (_WgradJob * len(jobs))()
+        for a, (U, ldu, V, ldv, C, P, Q, param) in zip(arr, jobs):
+            g = param.grad
+            if g is not None and g.data_ptr() != C:
+                # autograd did not adopt the tensor handed to it but copied it (its memory may be gone): the
+                # product goes where the gradient now lives
+                if g.dtype != torch.float32 or not g.is_contiguous() or tuple(g.shape) != (P, Q):
+                    raise RuntimeError("deferred weight gradient: the parameter's .grad is not the fp32 [P, Q] tensor "
+                                       "the backward pass handed to autograd (set_defer_wgrad(False) for this setup)")
+                C = g.data_ptr()
+            a.U, a.ldu, a.V, a.ldv, a.C, a.ldc, a.P, a.Q = U, ldu, V, ldv, C, Q, P, Q
+        with torch.cuda.device(device):
+            ws = _ws(lib.vitmi_gemm_wgrad_multi_workspace_bytes(_ct.addressof(arr), len(jobs), rows), device)
+            check(lib.vitmi_gemm_wgrad_multi(_ct.addressof(arr), len(jobs), rows, _p(ws), stream), "vitmi_gemm_wgrad_multi")
+    del keep
+
+
 class _BlockFn(torch.autograd.Function):
     """Base of the two sub-block nodes.  forward() always runs with grad mode off and ctx.needs_input_grad only
     mirrors requires_grad of the inputs, so whether a graph is being built is sampled where apply() is called."""
@@ -1148,11 +1225,17 @@ class AttnBlockFn(_BlockFn):
             if nbytes is None:
                 nbytes = _block_ws_bytes[key] = int(lib.vitmi_attn_block_bwd_workspace_bytes(_dt(cdt), B, N, D, heads, dh))
             ws = _ws(nbytes, dev)
+            defer = D % 8 == 0 and inner % 8 == 0 and _defer_ok(cdt, rows, D, (w_qkv, w_out))
             check(lib.vitmi_attn_block_bwd(_dt(cdt), B, N, D, heads, dh, _p(dy2), _p(x2), _p(xn), _p(qkv), _p(o), _p(lse),
                                            _p(g), _p(mean), _p(rstd), _p(compute_copy(w_qkv, cdt)),
                                            _p(weight_t(w_qkv, cdt)), _p(compute_copy(w_out, cdt)),
-                                           _p(weight_t(w_out, cdt)), _p(dx), _p(dg), _p(db), _p(dwq), _p(dbq), _p(dwo),
+                                           _p(weight_t(w_out, cdt)), _p(dx), _p(dg), _p(db),
+                                           None if defer else _p(dwq), _p(dbq), None if defer else _p(dwo),
                                            _p(dbo), _p(ws), ctx.qkv_layout, _stream()), "vitmi_attn_block_bwd")
+            if defer:
+                dqkv = ws.data_ptr() + lib.vitmi_attn_block_bwd_dqkv_offset(_dt(cdt), B, N, D, heads, dh)
+                _defer_jobs(rows, dev, [(_p(dy2), D, _p(o), inner, _p(dwo), D, inner, w_out),
+                                        (dqkv, 3 * inner, _p(xn), D, _p(dwq), 3 * inner, D, w_qkv)], (dy2, o, xn, ws))
             dx = dx.view(B, N, D)
             if dx.dtype != in_dtype:
                 dx = cast(dx, in_dtype)
@@ -1341,10 +1424,16 @@ class FFBlockFn(_BlockFn):
             if nbytes is None:
                 nbytes = _block_ws_bytes[key] = int(lib.vitmi_ff_block_bwd_workspace_bytes(_dt(cdt), rows, D, M))
             ws = _ws(nbytes, dev)
+            defer = D % 8 == 0 and M % 8 == 0 and _defer_ok(cdt, rows, D, (w1, w2))
             check(lib.vitmi_ff_block_bwd(_dt(cdt), rows, D, M, _p(dy2), _p(x2), _p(xn), _p(u), _p(h), _p(g), _p(mean),
                                          _p(rstd), _p(compute_copy(w1, cdt)), _p(weight_t(w1, cdt)),
                                          _p(compute_copy(w2, cdt)), _p(weight_t(w2, cdt)), _p(dx), _p(dg), _p(db),
-                                         _p(dw1), _p(db1), _p(dw2), _p(db2), _p(ws), _stream()), "vitmi_ff_block_bwd")
+                                         None if defer else _p(dw1), _p(db1), None if defer else _p(dw2), _p(db2),
+                                         _p(ws), _stream()), "vitmi_ff_block_bwd")
+            if defer:
+                du = ws.data_ptr() + lib.vitmi_ff_block_bwd_du_offset(_dt(cdt), rows, D, M)
+                _defer_jobs(rows, dev, [(_p(dy2), D, _p(h), M, _p(dw2), D, M, w2), (du, M, _p(xn), D, _p(dw1), M, D, w1)],
+                            (dy2, h, xn, ws))
             dx = dx.view(shape)
             if dx.dtype != in_dtype:
                 dx = cast(dx, in_dtype)
