@@ -300,25 +300,33 @@ __global__ __launch_bounds__(SM_THREADS) void ff_small_bwd_kernel(FfSmallBwdArgs
 }
 
 // out[c] = sum over the strips' rows of partial[strip][c], in strip order; c runs over [db1 (M) | dgamma | dbeta | db2 (D each)]
-__global__ __launch_bounds__(256) void ff_small_bwd_final_kernel(const float* __restrict__ partial, int strips, int M, int D,
-                                                                 float* __restrict__ db1, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta, float* __restrict__ db2) {
+__global__ __launch_bounds__(1024) void ff_small_bwd_final_kernel(const float* __restrict__ partial, int strips, int M, int D,
+                                                                  float* __restrict__ db1, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, float* __restrict__ db2) {
+    // 16 row groups x 64 columns; a group keeps four independent running sums so that its loads overlap (the sums
+    // are taken in a fixed order either way)
     const int cols = M + 3 * D;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
-    float a0 = 0.f, a1 = 0.f;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < cols) {
+        const float* p = partial + c;
         int k = grp;
-        for (; k + 4 < strips; k += 8) {
-            a0 += partial[(long long)k * cols + c];
-            a1 += partial[(long long)(k + 4) * cols + c];
+        for (; k + 48 < strips; k += 64) {
+            a0 += p[(long long)k * cols];
+            a1 += p[(long long)(k + 16) * cols];
+            a2 += p[(long long)(k + 32) * cols];
+            a3 += p[(long long)(k + 48) * cols];
         }
-        if (k < strips) a0 += partial[(long long)k * cols + c];
+        for (; k < strips; k += 16) a0 += p[(long long)k * cols];
     }
-    __shared__ float red[4][64];
-    red[grp][threadIdx.x & 63] = a0 + a1;
+    __shared__ float red[16][64];
+    red[grp][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (grp == 0 && c < cols) {
-        const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s += red[g][lane];
         if (c < M)
             db1[c] = s;
         else if (c < M + D)
@@ -495,7 +503,7 @@ int vitmi_ff_small_bwd_final(long long rows, int D, int M, const float* partial,
                              float* db2, void* stream) {
     const int mt = ff_small_bwd_tiles(rows, D, M);
     const int strips = (int)((rows + mt * 16 - 1) / (mt * 16));
-    hipLaunchKernelGGL(ff_small_bwd_final_kernel, dim3((M + 3 * D + 63) / 64), dim3(256), 0, as_stream(stream), partial, strips, M,
+    hipLaunchKernelGGL(ff_small_bwd_final_kernel, dim3((M + 3 * D + 63) / 64), dim3(1024), 0, as_stream(stream), partial, strips, M,
                        D, db1, dgamma, dbeta, db2);
     VITMI_LAUNCH_CHECK("ff_small_bwd_final_kernel");
     return VITMI_OK;
