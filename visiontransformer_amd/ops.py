@@ -999,7 +999,7 @@ class _WgradJob(_ct.Structure):
 
 
 _defer_wgrad = os.environ.get("VITMI_DEFER_WGRAD", "1") != "0"
-_deferred = {"task": None, "groups": {}, "keep": []}
+_deferred = {}      # graph task id -> {"groups": {(device, rows, stream): [jobs]}, "keep": [tensors]}
 deferred_stats = {"jobs": 0, "flushes": 0}     # running totals, for tests and diagnostics
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
 
@@ -1024,23 +1024,27 @@ def _defer_ok(cdt, rows, D, params):
 def _defer_jobs(rows, device, jobs, keep):
     """jobs: (U ptr, ldu, V ptr, ldv, C ptr, P, Q, parameter) over `rows` tokens; keep: tensors the operands live in.
     The result tensor itself is NOT kept: a second reference would make autograd's AccumulateGrad copy it (still
-    empty) instead of adopting it as the parameter's .grad."""
+    empty) instead of adopting it as the parameter's .grad.  The queue belongs to the running autograd pass (a pass
+    started from inside another one, as reentrant checkpointing does, has its own)."""
     task = _graph_task_id()
-    st = _deferred
-    if st["task"] != task:
+    st = _deferred.get(task)
+    if st is None:
         # a pass that ended without its callback (an exception) leaves jobs that will never be wanted
-        st["task"], st["groups"], st["keep"] = task, {}, []
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_deferred)
+        for old in [t for t in _deferred if t < task - 64]:
+            del _deferred[old]
+        st = _deferred[task] = {"groups": {}, "keep": []}
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: _flush_deferred(task))
     st["groups"].setdefault((device, rows, _stream()), []).extend(jobs)
-    deferred_stats["jobs"] += len(jobs)
     st["keep"].extend(keep)
+    deferred_stats["jobs"] += len(jobs)
 
 
-def _flush_deferred():
-    st = _deferred
-    groups, st["groups"], keep, st["keep"], st["task"] = st["groups"], {}, st["keep"], [], None
+def _flush_deferred(task):
+    st = _deferred.pop(task, None)
+    if st is None:
+        return
     deferred_stats["flushes"] += 1
-    for (device, rows, stream), jobs in groups.items():
+    for (device, rows, stream), jobs in st["groups"].items():
         arr = (_WgradJob * len(jobs))()
         for a, (U, ldu, V, ldv, C, P, Q, param) in zip(arr, jobs):
             g = param.grad
@@ -1055,7 +1059,6 @@ def _flush_deferred():
         with torch.cuda.device(device):
             ws = _ws(lib.vitmi_gemm_wgrad_multi_workspace_bytes(_ct.addressof(arr), len(jobs), rows), device)
             check(lib.vitmi_gemm_wgrad_multi(_ct.addressof(arr), len(jobs), rows, _p(ws), stream), "vitmi_gemm_wgrad_multi")
-    del keep
 
 
 class _BlockFn(torch.autograd.Function):
