@@ -984,8 +984,8 @@ class LinearFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # weight gradients of the small geometry, gathered after the backward pass
 # ---------------------------------------------------------------------------------------------
-# At widths where a sub-block's products are a few microseconds each (the 32-pixel models), its two weight-gradient
-# products are not launched by the sub-block's backward call: they are queued, and one vitmi_gemm_wgrad_multi call at
+# At embedding widths up to 512 (the 32-pixel models, ViT-S/16) a sub-block's two weight-gradient products are not
+# launched by the sub-block's backward call: they are queued, and one vitmi_gemm_wgrad_multi call at
 # the end of the autograd pass (an engine callback) forms all of them, 16 products per launch.  The gradient tensors
 # handed to autograd in between are allocated but not yet filled, so the queue is used only when nothing reads them
 # before the pass ends: the parameter has no gradient to accumulate into and no hooks (a GradReducer's buckets, a
@@ -999,6 +999,9 @@ class _WgradJob(_ct.Structure):
 
 
 _defer_wgrad = os.environ.get("VITMI_DEFER_WGRAD", "1") != "0"
+# widths whose weight matrices are a few 128 x 128 tiles each (ViT-S/16 and below): gathered, they fill the chip
+# without token slabs; from ViT-B/16 on the paired 256 x 256 launches of the sub-block calls are the faster form
+_DEFER_MAX_WIDTH = 512
 _deferred = {}      # graph task id -> {"groups": {(device, rows, stream): [jobs]}, "keep": [tensors]}
 deferred_stats = {"jobs": 0, "flushes": 0}     # running totals, for tests and diagnostics
 _graph_task_id = getattr(torch._C, "_current_graph_task_id", None)
@@ -1010,7 +1013,7 @@ def set_defer_wgrad(on):
 
 
 def _defer_ok(cdt, rows, D, params):
-    if not _defer_wgrad or cdt != torch.bfloat16 or rows * D > (8 << 20) or _graph_task_id is None:
+    if not _defer_wgrad or cdt != torch.bfloat16 or D > _DEFER_MAX_WIDTH or _graph_task_id is None:
         return False
     if _graph_task_id() < 0:
         return False
