@@ -249,6 +249,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+            if local_world > torch.cuda.device_count():
+                raise SystemExit(f"bench.py: {local_world} ranks on this node but {torch.cuda.device_count()} GPU(s) visible; "
+                                 "RCCL needs one GPU per rank (VITMI_DIST_BACKEND=gloo rehearses N > 1 on one card)")
             # The GEMMs and the attention backward keep every CU full (one workgroup with most of the register file
             # and LDS per CU), and a collective's workgroups cannot share a CU with them: every CU a collective
             # holds delays one block of the next persistent launch until the others have finished.  So the

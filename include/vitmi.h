@@ -398,8 +398,9 @@ int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const voi
  * operands) the block calls run as one-launch kernels that keep the sub-block's activations in LDS; same outputs to the
  * bf16 bar.  vitmi_debug_set_small_fused(mask): bit 0 = the MLP sub-block's forward, bit 1 = the attention
  * sub-block's forward (up to 96 tokens, heads of 8 or 16, no probability export), bit 2 = the MLP sub-block's backward,
- * bit 3 = that backward kernel in calls that leave the weight gradients to the caller (dw1 == dw2 == NULL)
- * (default 11: the two forward kernels and bit 3; a negative mask restores the default);
+ * bit 3 = that backward kernel in calls that leave the weight gradients to the caller (dw1 == dw2 == NULL), bit 4 = the
+ * attention sub-block's backward in such calls (dw_qkv == dw_out == NULL, no qkv bias, both transposed weight copies given)
+ * (default 27: the two forward kernels and bits 3 and 4; a negative mask restores the default);
  * process-wide, for benchmarking and for the tests that compare the two forms. */
 int vitmi_debug_set_small_fused(int mask);
 /* The two weight-gradient products of a sub-block's backward call may run on a second stream of the library's own,

@@ -211,6 +211,58 @@ def test_ff_block_backward_one_launch_against_steps_and_fp64(rows, D, M, erf):
         assert rel_err(fused[k].double(), v) < 2e-2, k
 
 
+def _attn_block_bwd(B, N, D, H, DH, fused, seed=0):
+    """vitmi_attn_block_bwd in the form that leaves the weight gradients to the caller (both null), from the saved
+    tensors of the launch-per-step forward; dqkv is read back from its place in the workspace."""
+    from visiontransformer_amd._lib import check, lib
+    from visiontransformer_amd.ops import _p, _stream
+    I = H * DH
+    ins, fwd = _attn_block(B, N, D, H, DH, False, False, seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    dy = (torch.randn(B * N, D, generator=g) * 0.1).to(DEV, BF)
+    wq_t, wo_t = ins["wq"].t().contiguous(), ins["wo"].t().contiguous()
+    out = dict(dx=torch.empty(B * N, D, dtype=BF, device=DEV), dgamma=torch.empty(D, device=DEV),
+               dbeta=torch.empty(D, device=DEV), db_out=torch.empty(D, device=DEV))
+    ws = torch.zeros(int(lib.vitmi_attn_block_bwd_workspace_bytes(1, B, N, D, H, DH)) + 256, dtype=torch.uint8, device=DEV)
+    check(lib.vitmi_debug_set_small_fused(27 if fused else 11))
+    try:
+        check(lib.vitmi_attn_block_bwd(1, B, N, D, H, DH, _p(dy), _p(ins["x"]), _p(fwd["xn"]), _p(fwd["qkv"]), _p(fwd["o"]),
+                                       _p(fwd["lse"]), _p(ins["gamma"]), _p(fwd["mean"]), _p(fwd["rstd"]), _p(ins["wq"]),
+                                       _p(wq_t), _p(ins["wo"]), _p(wo_t), _p(out["dx"]), _p(out["dgamma"]), _p(out["dbeta"]),
+                                       None, None, None, _p(out["db_out"]), _p(ws), 0, _stream()), "vitmi_attn_block_bwd")
+        torch.cuda.synchronize()
+    finally:
+        check(lib.vitmi_debug_set_small_fused(-1))
+    off = int(lib.vitmi_attn_block_bwd_dqkv_offset(1, B, N, D, H, DH))
+    out["dqkv"] = ws[off:off + B * N * 3 * I * 2].view(BF).reshape(B * N, 3 * I).clone()
+    return ins, fwd, dy, out
+
+
+@pytest.mark.parametrize("B,N,D,H,DH", [(256, 65, 192, 12, 8), (4, 33, 192, 12, 8), (3, 17, 64, 4, 8), (2, 96, 256, 16, 16),
+                                        (2, 50, 128, 4, 16), (5, 1, 64, 4, 8), (2, 81, 96, 4, 8)])
+def test_attention_block_backward_one_launch_against_steps_and_fp64(B, N, D, H, DH):
+    ins, fwd, dy, fused = _attn_block_bwd(B, N, D, H, DH, True)
+    _, _, _, steps = _attn_block_bwd(B, N, D, H, DH, False)
+    # against the launch-per-step form: dO and dxn are not rounded to bf16 on their way through HBM here
+    for k in ("dx", "dgamma", "dbeta", "db_out", "dqkv"):
+        assert rel_err(fused[k].float(), steps[k].float()) < 1e-2, k
+    # fp64 evaluation through autograd from the same bf16 operands
+    I = H * DH
+    x = ins["x"].double().requires_grad_(True)
+    gamma, beta = ins["gamma"].double().requires_grad_(True), ins["beta"].double().requires_grad_(True)
+    wq, wo, bo = ins["wq"].double(), ins["wo"].double(), ins["bo"].double().requires_grad_(True)
+    xn = torch.nn.functional.layer_norm(x, (D,), gamma, beta, 1e-5)
+    qkv = xn @ wq.t()
+    qkv.retain_grad()
+    q_, k_, v_ = (t.reshape(B, N, H, DH).permute(0, 2, 1, 3) for t in qkv.split(I, dim=-1))
+    o = (torch.softmax((q_ @ k_.transpose(-1, -2)) * DH ** -0.5, -1) @ v_).permute(0, 2, 1, 3).reshape(B * N, I)
+    y = o @ wo.t() + bo + x
+    y.backward(dy.double())
+    ref = dict(dx=x.grad, dgamma=gamma.grad, dbeta=beta.grad, db_out=bo.grad, dqkv=qkv.grad)
+    for k, v in ref.items():
+        assert rel_err(fused[k].double(), v) < 2e-2, k
+
+
 def test_wgrad_multi_against_single_products():
     """vitmi_gemm_wgrad_multi: 20 jobs over one token axis (two launches of up to 16), ragged 128 x 128 tiles, with the
     slab workspace and without it, against the fp32 products of the bf16 operands and the one-product entry point."""

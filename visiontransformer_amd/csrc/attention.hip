@@ -503,6 +503,321 @@ __global__ __launch_bounds__(SM_THREADS) void attn_small_fwd_kernel(AttnSmallArg
     }
 }
 
+// ================================================================ attention sub-block backward in one launch (small geometry)
+// The backward of attn_small_fwd_kernel's sub-block (mymodel/ViT.py:52-58, 77-104, 119) for one image per workgroup, for
+// callers that form the weight gradients themselves:
+//   dO   = dy Wo                      -> per-head LDS images (bf16), delta = rowsum(dO * O) beside them
+//   dq, dk, dv from the q, k, v, dO images (the tile arithmetic of attn_bwd_dq_bf16_kernel / attn_bwd_dkv_bf16_kernel,
+//                                        every operand in LDS) -> rows of dqkv in LDS and in HBM (operand of dWqkv)
+//   dxn  = dqkv Wqkv                  -> stays in registers (fp32)
+//   dx   = LayerNorm backward of dxn at x, + dy (the residual branch)
+// and the image's column sums for dgamma, dbeta (of dxn) and the output bias (of dy) as one row of `partial` ([B][3 D]).
+// Wo and Wqkv are read through their transposed copies ([I][D] and [D][3 I]: the output feature of each product indexes
+// a row).
+// Fragments for the products over a head dimension of 8 or 16 inside a 32-deep MFMA, without a branch: the operand that
+// is fixed for a tile is zero beyond the head dimension (row_frag_z), so the streamed one may hold anything finite
+// there; its lane groups past the head dimension re-read a piece inside it (row_frag_any).
+template <int DH>
+__device__ __forceinline__ bf16x8 row_frag_any(const bf16_t* img, int row, int fg) {
+    return *reinterpret_cast<const bf16x8*>(img + img_off<DH>(row, fg & (DH / 8 - 1)));
+}
+template <int DH>
+__device__ __forceinline__ bf16x8 row_frag_z(const bf16_t* img, int row, int fg) {
+    union {
+        bf16x8 v;
+        u32x4 w;
+    } u;
+    u.v = row_frag_any<DH>(img, row, fg);
+    const unsigned keep = fg * 8 < DH ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u.w[i] &= keep;
+    return u.v;
+}
+
+struct AttnSmallBwdArgs {
+    const bf16_t *dy, *x, *qkv, *o;
+    const float *lse, *gamma, *mean, *rstd;
+    const bf16_t *w_out_t, *w_qkv_t;
+    bf16_t *dqkv, *dx;
+    float* partial;
+    int N, D, H;
+};
+
+#ifndef VITMI_ASB_ABL
+#define VITMI_ASB_ABL 0   // timing ablations: 1 = no softmax backward, 2 = no dO product, 4 = no dxn product
+#endif
+template <int DH, int NC, int MT>
+__global__ __launch_bounds__(SM_THREADS) void attn_small_bwd_kernel(AttnSmallBwdArgs a) {
+    using A = AttnDims<DH>;
+    constexpr int NP = NC * 32, IMG = NP * DH, R = MT * 16;
+    static_assert(R <= NP, "the row strip must fit the images");
+    static_assert(A::KS == 1 && A::DT == 1, "heads of 8 or 16");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int N = a.N, D = a.D, H = a.H, I = H * DH, ldx = D + SM_PAD, ldq = 3 * I + SM_PAD;
+    bf16_t* act = reinterpret_cast<bf16_t*>(smem);            // [R][ldx] dy rows, later [R][ldq] dqkv rows
+    bf16_t* imgs = act + R * (ldx > ldq ? ldx : ldq);         // [4][H][NP][DH] q, k, v, dO images (+ one row of slack)
+    float* lse2 = reinterpret_cast<float*>(imgs + 4 * H * IMG + 8);   // [H][NP] in log2 units, then delta [H][NP]
+    float* delta = lse2 + H * NP;
+    float* red = delta + H * NP;                              // [2][SM_WAVES][R] row sums of the LayerNorm backward
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tok = lane & 15, f8 = (lane >> 4) * 8;
+    const int b = blockIdx.x;
+    const long long row0 = (long long)b * N;
+    // ---- the image's dy rows, its q, k, v images and log-sum-exps into LDS (zeros past the last token); the dy loads
+    // are in flight while the images are staged
+    {
+        constexpr int DYB = 6;   // R (D / 8) <= 96 * 32 pieces of 16 bytes over 512 threads
+        u32x4 dv[DYB];
+#pragma unroll
+        for (int j = 0; j < DYB; ++j) {
+            const int i = threadIdx.x + j * SM_THREADS, r = i / (D / 8), c = (i - r * (D / 8)) * 8;
+            dv[j] = u32x4{0u, 0u, 0u, 0u};
+            if (i < R * (D / 8) && r < N) dv[j] = *reinterpret_cast<const u32x4*>(a.dy + (row0 + r) * D + c);
+        }
+        const int cpr = 3 * I / 8;
+        for (int i0 = threadIdx.x; i0 < NP * cpr; i0 += 8 * SM_THREADS) {
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * SM_THREADS, r = i / cpr, n = (i - r * cpr) * 8;
+                v[j] = u32x4{0u, 0u, 0u, 0u};
+                if (i < NP * cpr && r < N) v[j] = *reinterpret_cast<const u32x4*>(a.qkv + (row0 + r) * 3 * I + n);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * SM_THREADS, r = i / cpr, n = (i - r * cpr) * 8;
+                const int which = n / I, rem = n - which * I, h = rem / DH, d0 = rem - h * DH;
+                if (i < NP * cpr) *reinterpret_cast<u32x4*>(imgs + (which * H + h) * IMG + img_off<DH>(r, d0 >> 3)) = v[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < DYB; ++j) {
+            const int i = threadIdx.x + j * SM_THREADS, r = i / (D / 8), c = (i - r * (D / 8)) * 8;
+            if (i < R * (D / 8)) *reinterpret_cast<u32x4*>(act + r * ldx + c) = dv[j];
+        }
+        for (int i = threadIdx.x; i < H * NP; i += SM_THREADS) {
+            const int h = i / NP, q = i - h * NP;
+            lse2[i] = q < N ? a.lse[((long long)b * H + h) * N + q] * LOG2E : 1e30f;   // padded queries get p = 0
+            if (q >= R) delta[i] = 0.f;                                                  // (and no NaN from their delta)
+        }
+        // rows of the dO images that the product below does not write, and the slack row
+        if (R < NP) {
+            constexpr int CPR = DH / 8, EXTRA = (NP - R) * CPR;
+            for (int i = threadIdx.x; i < H * EXTRA; i += SM_THREADS) {
+                const int h = i / (EXTRA > 0 ? EXTRA : 1), rem = i - h * EXTRA;
+                *reinterpret_cast<u32x4*>(imgs + (3 * H + h) * IMG + R * DH + rem * 8) = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+        if (threadIdx.x == 0) *reinterpret_cast<u32x4*>(imgs + 4 * H * IMG) = u32x4{0u, 0u, 0u, 0u};
+    }
+    __syncthreads();
+    // ---- dO = dy Wo: 32 features per wave and pass, a lane's 8 consecutive ones lie in one head
+    for (int p = wave; p < I / 32 && !(VITMI_ASB_ABL & 2); p += SM_WAVES) {
+        f32x4 acc[2][MT];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int n = p * 32 + f8;
+        bf16x8 oq[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok;
+            oq[m] = zero8();
+            if (r < N) oq[m] = *reinterpret_cast<const bf16x8*>(a.o + (row0 + r) * I + n);
+        }
+        rows_gemm<MT, 2, 3>(a.w_out_t, D, p * 32, D / 32, act, ldx, lane, acc);
+        const int h = n / DH, d0 = n - h * DH;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok;
+            bf16x8 v;
+            float dl = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                v[t] = (bf16_t)acc[t >> 2][m][t & 3];   // rows past the last token: dy = 0, so 0
+                dl += (float)v[t] * (float)oq[m][t];
+            }
+            if (DH == 16) dl += __shfl_xor(dl, 16, 64);
+            *reinterpret_cast<bf16x8*>(imgs + (3 * H + h) * IMG + img_off<DH>(r, d0 >> 3)) = v;
+            if (d0 == 0) delta[h * NP + r] = dl;
+        }
+    }
+    __syncthreads();
+    // ---- softmax backward: (head, 16 queries) tiles for dq and (head, 16 keys) tiles for dk and dv, over the waves
+    {
+        const int fr = lane & 15, fg = lane >> 4;
+        const float scale = 1.0f / sqrtf((float)DH);
+        const float sl2 = scale * LOG2E, lscale = __log2f(scale);
+        // a wave's pass holds one tile of each kind (queries 16 tl .. of head h for dq, keys 16 tl .. for dk and dv): two
+        // independent chains of products and exponentials in one block of straight-line code, stored together at its end
+        for (int t = wave; t < H * MT && !(VITMI_ASB_ABL & 1); t += SM_WAVES) {
+            const int h = t / MT, tl = t - h * MT;
+            const bf16_t* Qs = imgs + h * IMG;
+            const bf16_t* Ks = imgs + (H + h) * IMG;
+            const bf16_t* Vs = imgs + (2 * H + h) * IMG;
+            const bf16_t* dOs = imgs + (3 * H + h) * IMG;
+            const float* l2p = lse2 + h * NP;
+            const float* dlp = delta + h * NP;
+            const int row = tl * 16 + fr;                      // the query of the dq tile, the key of the dk / dv tile
+            const bf16x8 qf = row_frag_z<DH>(Qs, row, fg), dof = row_frag_z<DH>(dOs, row, fg);
+            const bf16x8 kf = row_frag_z<DH>(Ks, row, fg), vf = row_frag_z<DH>(Vs, row, fg);
+            // p * 1/sqrt(dh) comes straight out of the exponential: log2 of the factor joins the exponent
+            const float l2q = l2p[row] - lscale, dlq = dlp[row];
+            f32x4 dqt = {0.f, 0.f, 0.f, 0.f}, dkt = dqt, dvt = dqt;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                f32x4 ds[2];
+                bf16x8 pf, dsk;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int prow = perm_row(c, u, fr);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    // scores and dP with the tile's queries on the lanes (keys prow) ...
+                    const f32x4 sq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag_any<DH>(Ks, prow, fg), qf, z, 0, 0, 0);
+                    const f32x4 dpq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag_any<DH>(Vs, prow, fg), dof, z, 0, 0, 0);
+                    // ... and with the tile's keys on the lanes (queries prow)
+                    const f32x4 sk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag_any<DH>(Qs, prow, fg), kf, z, 0, 0, 0);
+                    const f32x4 dpk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(row_frag_any<DH>(dOs, prow, fg), vf, z, 0, 0, 0);
+                    const int q0 = 32 * c + 8 * fg + 4 * u;      // the key-tile lane's rows are queries q0 + r
+                    const f32x4 l2 = *reinterpret_cast<const f32x4*>(&l2p[q0]);
+                    const f32x4 dl = *reinterpret_cast<const f32x4*>(&dlp[q0]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ds[u][r] = __builtin_amdgcn_exp2f(fmaf(sq[r], sl2, -l2q)) * (dpq[r] - dlq);
+                        const float pr = __builtin_amdgcn_exp2f(fmaf(sk[r], sl2, -l2[r]));
+                        pf[4 * u + r] = (bf16_t)pr;
+                        dsk[4 * u + r] = (bf16_t)(pr * (dpk[r] - dl[r]));   // the 1/sqrt(dh) goes onto the finished dK
+                    }
+                }
+                bf16x8 dsf = pack8(ds[0], ds[1]);                 // element j of the fragment is key 32c + 8fg + j
+                // keys past N contribute nothing (only the last chunk can reach past N: NC = ceil(N / 32))
+                if (c == NC - 1) dsf = keep_first(dsf, N - 32 * c - 8 * fg);
+                dqt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Ks, 32 * c, 0, lane), dsf, dqt, 0, 0, 0);
+                dvt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(dOs, 32 * c, 0, lane), pf, dvt, 0, 0, 0);
+                dkt = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<DH>(Qs, 32 * c, 0, lane), dsk, dkt, 0, 0, 0);
+            }
+            const int d = fg * 4;
+            if (d < DH) {
+                bf16x4 vq, vk, vv;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    vq[r] = row < N ? (bf16_t)dqt[r] : (bf16_t)0.f;
+                    vk[r] = row < N ? (bf16_t)(dkt[r] * scale) : (bf16_t)0.f;
+                    vv[r] = row < N ? (bf16_t)dvt[r] : (bf16_t)0.f;
+                }
+                bf16_t* dst = act + row * ldq + h * DH + d;
+                *reinterpret_cast<bf16x4*>(dst) = vq;
+                *reinterpret_cast<bf16x4*>(dst + I) = vk;
+                *reinterpret_cast<bf16x4*>(dst + 2 * I) = vv;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the dqkv rows out (the caller's weight gradient reads them): by the waves without a 32-feature pass below
+    const int pass_waves = D / 32;
+    {
+        const int first = pass_waves < SM_WAVES ? (int)threadIdx.x - pass_waves * 64 : (int)threadIdx.x;
+        const int count = pass_waves < SM_WAVES ? SM_THREADS - pass_waves * 64 : SM_THREADS;
+        const int cpr = 3 * I / 8;
+        if (first >= 0)
+            for (int i = first; i < N * cpr; i += count) {
+                const int r = i / cpr, c = (i - r * cpr) * 8;
+                *reinterpret_cast<u32x4*>(a.dqkv + (row0 + r) * 3 * I + c) = *reinterpret_cast<const u32x4*>(act + r * ldq + c);
+            }
+    }
+    // ---- dxn = dqkv Wqkv: one 32-feature pass per wave (D <= 256), then the LayerNorm backward across the waves
+    const bool active = wave < pass_waves;
+    const int n = wave * 32 + f8;
+    f32x4 acc[2][MT];
+    bf16x8 xq[MT], dyq[MT];
+    float mu[MT], rs[MT];
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok < N ? m * 16 + tok : 0;
+            xq[m] = *reinterpret_cast<const bf16x8*>(a.x + (row0 + r) * D + n);
+            dyq[m] = *reinterpret_cast<const bf16x8*>(a.dy + (row0 + r) * D + n);
+            mu[m] = a.mean[row0 + r];
+            rs[m] = a.rstd[row0 + r];
+        }
+        g0 = *reinterpret_cast<const f32x4*>(a.gamma + n);
+        g1 = *reinterpret_cast<const f32x4*>(a.gamma + n + 4);
+        if (!(VITMI_ASB_ABL & 4)) rows_gemm<MT, 2, 3>(a.w_qkv_t, 3 * I, wave * 32, 3 * I / 32, act, ldq, lane, acc);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float xh = ((float)xq[m][t] - mu[m]) * rs[m];
+                const float g = acc[t >> 2][m][t & 3] * (t < 4 ? g0[t & 3] : g1[t & 3]);
+                s1 += g;
+                s2 += g * xh;
+            }
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lane < 16) {
+                red[wave * R + m * 16 + tok] = s1;
+                red[(SM_WAVES + wave) * R + m * 16 + tok] = s2;
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+        float dg[8], db[8], dr[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) dg[t] = db[t] = dr[t] = 0.f;
+        float* part = a.partial + (long long)b * 3 * D;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int r = m * 16 + tok;
+            float c1 = 0.f, c2 = 0.f;
+            for (int w = 0; w < pass_waves; ++w) {
+                c1 += red[w * R + r];
+                c2 += red[(SM_WAVES + w) * R + r];
+            }
+            c1 /= (float)D;
+            c2 /= (float)D;
+            bf16x8 o;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float xh = ((float)xq[m][t] - mu[m]) * rs[m];
+                const float dxn = acc[t >> 2][m][t & 3];   // rows past the last token: dqkv = 0, so 0
+                const float g = dxn * (t < 4 ? g0[t & 3] : g1[t & 3]);
+                const float res = r < N ? (float)dyq[m][t] : 0.f;
+                o[t] = (bf16_t)(rs[m] * (g - c1 - xh * c2) + res);
+                dg[t] += dxn * xh;
+                db[t] += dxn;
+                dr[t] += res;
+            }
+            if (r < N) *reinterpret_cast<bf16x8*>(a.dx + (row0 + r) * D + n) = o;
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                dg[t] += __shfl_xor(dg[t], o, 64);
+                db[t] += __shfl_xor(db[t], o, 64);
+                dr[t] += __shfl_xor(dr[t], o, 64);
+            }
+        if (tok == 0) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                part[n + t] = dg[t];
+                part[D + n + t] = db[t];
+                part[2 * D + n + t] = dr[t];
+            }
+        }
+    }
+}
+
 // ================================================================ backward dK, dV (bf16)
 template <int DH, int NC, int HPW>
 __global__ __launch_bounds__(ATTN_THREADS) void attn_bwd_dkv_bf16_kernel(const bf16_t* __restrict__ qkv,
@@ -2363,4 +2678,62 @@ int vitmi_attn_small_fwd(int B, int N, int D, int H, int DH, const void* x, cons
     hipStream_t s = as_stream(stream);
     ProfScope prof(VITMI_FAM_ATTN_FWD, s, 4.0 * B * H * (double)N * N * DH);
     return DH == 8 ? dispatch_attn_small<8>(a, B, s) : dispatch_attn_small<16>(a, B, s);
+}
+
+// ---------------------------------------------------------------- one-launch attention sub-block backward (small geometry)
+int vitmi_small_fused_mask();   // small.hip
+namespace {
+size_t attn_small_bwd_lds(int D, int H, int DH, int NC, int MT) {
+    const int I = H * DH, ld = (D > 3 * I ? D : 3 * I) + SM_PAD;
+    return ((size_t)MT * 16 * ld + (size_t)4 * H * NC * 32 * DH + 8) * sizeof(bf16_t) +
+           ((size_t)2 * H * NC * 32 + (size_t)2 * SM_WAVES * MT * 16) * sizeof(float);
+}
+template <int DH, int NC, int MT>
+int launch_attn_small_bwd(const AttnSmallBwdArgs& a, int B, hipStream_t s) {
+    static unsigned long long done = 0;
+    const size_t lds = attn_small_bwd_lds(a.D, a.H, DH, NC, MT);
+    int rc = ensure_lds(reinterpret_cast<const void*>(&attn_small_bwd_kernel<DH, NC, MT>), LDS_BYTES, &done,
+                        "vitmi_attn_block_bwd: LDS attribute");
+    if (rc != VITMI_OK) return rc;
+    hipLaunchKernelGGL((attn_small_bwd_kernel<DH, NC, MT>), dim3(B), dim3(SM_THREADS), lds, s, a);
+    VITMI_LAUNCH_CHECK("attn_small_bwd_kernel");
+    return VITMI_OK;
+}
+template <int DH>
+int dispatch_attn_small_bwd(const AttnSmallBwdArgs& a, int B, hipStream_t s) {
+    const int mt = (a.N + 15) / 16;
+    if (mt <= 2) return launch_attn_small_bwd<DH, 1, 2>(a, B, s);
+    if (mt == 3) return launch_attn_small_bwd<DH, 2, 3>(a, B, s);
+    if (mt == 4) return launch_attn_small_bwd<DH, 2, 4>(a, B, s);
+    if (mt == 5) return launch_attn_small_bwd<DH, 3, 5>(a, B, s);
+    return launch_attn_small_bwd<DH, 3, 6>(a, B, s);
+}
+}  // namespace
+
+// whether vitmi_attn_block_bwd may run as the one-launch kernel when the caller forms the weight gradients (bit 4 of
+// the small-geometry mask; shape part: the operands' alignment is checked at the call)
+bool vitmi_attn_small_bwd_ok(int dt, int B, int N, int D, int H, int DH) {
+    if (!(vitmi_small_fused_mask() & 16) || dt != VITMI_BF16 || B <= 0 || N <= 0 || N > 96) return false;
+    if (DH != 8 && DH != 16) return false;
+    const int I = H * DH;
+    if (D < 32 || D > 256 || D % 32 != 0 || I % 32 != 0 || I > 256) return false;
+    const int mt = (N + 15) / 16 < 2 ? 2 : (N + 15) / 16;
+    return attn_small_bwd_lds(D, H, DH, (mt + 1) / 2, mt) <= LDS_BYTES;
+}
+// bytes of the per-image partial sums the kernel leaves for the final reduction (ff_small_bwd_final_kernel's layout
+// without a hidden part: [B][dgamma | dbeta | output-bias gradient])
+long long vitmi_attn_small_bwd_partial_bytes(int B, int D) { return B > 0 && D > 0 ? (long long)B * 3 * D * (long long)sizeof(float) : 0; }
+
+// returns 1000 (nothing enqueued) when an operand is not 16-byte aligned
+int vitmi_attn_small_bwd(int B, int N, int D, int H, int DH, const void* dy, const void* x, const void* qkv, const void* o,
+                         const float* lse, const float* gamma, const float* mean, const float* rstd, const void* w_out_t,
+                         const void* w_qkv_t, void* dqkv, void* dx, float* partial, void* stream) {
+    if (!(al16p(dy) && al16p(x) && al16p(qkv) && al16p(o) && al16p(gamma) && al16p(w_out_t) && al16p(w_qkv_t) && al16p(dqkv) &&
+          al16p(dx) && al16p(partial)))
+        return 1000;
+    AttnSmallBwdArgs a{(const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)qkv, (const bf16_t*)o, lse, gamma, mean, rstd,
+                       (const bf16_t*)w_out_t, (const bf16_t*)w_qkv_t, (bf16_t*)dqkv, (bf16_t*)dx, partial, N, D, H};
+    hipStream_t s = as_stream(stream);
+    ProfScope prof(VITMI_FAM_ATTN_BWD, s, 10.0 * B * H * (double)N * N * DH);
+    return DH == 8 ? dispatch_attn_small_bwd<8>(a, B, s) : dispatch_attn_small_bwd<16>(a, B, s);
 }

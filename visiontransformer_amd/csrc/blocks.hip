@@ -231,6 +231,12 @@ int vitmi_attn_small_fwd(int B, int N, int D, int H, int DH, const void* x, cons
                          const void* w_qkv, const float* b_qkv, const void* w_out, const float* b_out, void* xn, float* mean,
                          float* rstd, void* qkv, void* o, float* lse, void* y, void* stream);
 int vitmi_small_fused_mask();
+bool vitmi_attn_small_bwd_ok(int dt, int B, int N, int D, int H, int DH);
+long long vitmi_attn_small_bwd_partial_bytes(int B, int D);
+int vitmi_attn_small_bwd(int B, int N, int D, int H, int DH, const void* dy, const void* x, const void* qkv, const void* o,
+                         const float* lse, const float* gamma, const float* mean, const float* rstd, const void* w_out_t,
+                         const void* w_qkv_t, void* dqkv, void* dx, float* partial, void* stream);
+int vitmi_small_sums_final(int strips, int D, const float* partial, float* dgamma, float* dbeta, float* db, void* stream);
 bool vitmi_qkv_planes_ok(int dt, int B, int N, int D, int H, int DH, const void* x, const void* w_qkv, const void* qkv);
 int vitmi_gemm_to_planes(int T, int N, int K, const void* xn, const void* w, const float* bias, void* planes, void* stream);
 int vitmi_gemm_from_planes(int T, int D, int I3, const void* dqkv_planes, const void* w_t, void* dxn, void* stream);
@@ -288,6 +294,7 @@ static long long attn_chain_scratch(int dt, int B, int N, int D, int H, int DH) 
     long long scratch = vitmi_attn_bwd_workspace_bytes(dt, B, N, H, DH);
     scratch = max2(scratch, vitmi_colsum_workspace_bytes(rows, 3 * H * DH));
     scratch = max2(scratch, vitmi_layernorm_bwd_workspace_bytes(rows, D));
+    scratch = max2(scratch, vitmi_attn_small_bwd_partial_bytes(B, D));
     return align256(scratch);
 }
 
@@ -327,6 +334,16 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
     // dw_qkv == dw_out == null: the weight gradients are the caller's, later (vitmi_gemm_wgrad_multi), from dy, o, xn
     // and dqkv, which stays row-major at vitmi_attn_block_bwd_dqkv_offset in the workspace the caller keeps until then
     const bool skip_w = !dw_qkv;
+    if (skip_w && !db_qkv && !qkv_layout && w_qkv_t && w_out_t && vitmi_attn_small_bwd_ok(dt, B, N, D, H, DH)) {
+        // one launch for dO, the softmax backward, dxn and the LayerNorm backward (attention.hip); the sums for dgamma,
+        // dbeta and the output bias are finished by a small kernel
+        const int rc = vitmi_attn_small_bwd(B, N, D, H, DH, dy, x, qkv, o, lse, gamma, mean, rstd, w_out_t, w_qkv_t, dqkv, dx,
+                                            (float*)scratch, stream);
+        if (rc != VITMI_SMALL_NOT_TAKEN) {
+            if (rc != VITMI_OK) return rc;
+            return vitmi_small_sums_final(B, D, (const float*)scratch, dgamma, dbeta, db_out, stream);
+        }
+    }
     const bool dq_planes = !skip_w && (g_qkv_planes & 2) && !db_qkv && w_qkv_t &&
                            vitmi_qkv_planes_ok(dt, B, N, D, H, DH, xn, w_qkv_t, dqkv);
     Side* sd = (dq_planes || skip_w) ? nullptr : overlap_side(rows, D, stream);  // (planes: heads of 64, never a small shape)

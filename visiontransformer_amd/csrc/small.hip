@@ -333,7 +333,7 @@ __global__ __launch_bounds__(1024) void ff_small_bwd_final_kernel(const float* _
             dgamma[c - M] = s;
         else if (c < M + 2 * D)
             dbeta[c - M - D] = s;
-        else
+        else if (db2)
             db2[c - M - 2 * D] = s;
     }
 }
@@ -393,7 +393,7 @@ int launch_ff_small(const FfSmallArgs& a, hipStream_t s) {
 // (the backward kernel is opt-in: beside the weight gradients on the second stream it is no faster than the four
 // launches it replaces -- 3.29 -> 3.46 ms per step at the 32-pixel geometry, batch 256, graph replay; it saves host time
 // when the step is issued eagerly: 4.57 -> 4.45 ms)
-constexpr int SMALL_DEFAULT = 3 | 8;
+constexpr int SMALL_DEFAULT = 3 | 8 | 16;
 template <int MT>
 int launch_ff_small_bwd(const FfSmallBwdArgs& a, hipStream_t s) {
     const size_t lds = (size_t)MT * 16 * ((a.D + SM_PAD) + (a.M + SM_PAD)) * sizeof(bf16_t) + (size_t)2 * SM_WAVES * MT * 16 * sizeof(float);
@@ -424,7 +424,8 @@ int ff_small_bwd_tiles(long long rows, int D, int M) {
 }
 
 // bit 0: MLP sub-block forward, bit 1: attention sub-block forward, bit 2: MLP sub-block backward, bit 3: the same
-// backward kernel in calls that leave the weight gradients to the caller (nothing then runs beside it)
+// backward kernel in calls that leave the weight gradients to the caller (nothing then runs beside it), bit 4: attention
+// sub-block backward in such calls
 int g_small_fused = SMALL_DEFAULT;
 
 }  // namespace
@@ -505,6 +506,14 @@ int vitmi_ff_small_bwd_final(long long rows, int D, int M, const float* partial,
     const int strips = (int)((rows + mt * 16 - 1) / (mt * 16));
     hipLaunchKernelGGL(ff_small_bwd_final_kernel, dim3((M + 3 * D + 63) / 64), dim3(1024), 0, as_stream(stream), partial, strips, M,
                        D, db1, dgamma, dbeta, db2);
+    VITMI_LAUNCH_CHECK("ff_small_bwd_final_kernel");
+    return VITMI_OK;
+}
+// the same final reduction over `strips` rows of [dgamma | dbeta | db (D each)]: the attention sub-block's partial sums
+// (db == null: no output bias)
+int vitmi_small_sums_final(int strips, int D, const float* partial, float* dgamma, float* dbeta, float* db, void* stream) {
+    hipLaunchKernelGGL(ff_small_bwd_final_kernel, dim3((3 * D + 63) / 64), dim3(1024), 0, as_stream(stream), partial, strips, 0, D,
+                       nullptr, dgamma, dbeta, db);
     VITMI_LAUNCH_CHECK("ff_small_bwd_final_kernel");
     return VITMI_OK;
 }
