@@ -416,10 +416,12 @@ __global__ __launch_bounds__(SM_THREADS) void attn_small_fwd_kernel(AttnSmallArg
     {
         const bf16x8 z = zero8();
         constexpr int CPR = DH / 8;
-        const int extra = (NP - R) * CPR;
-        for (int i = threadIdx.x; i < 3 * H * extra; i += SM_THREADS) {
-            const int img = i / extra, rem = i - img * extra;
-            *reinterpret_cast<bf16x8*>(imgs + img * IMG + R * DH + rem * 8) = z;
+        constexpr int extra = (NP - R) * CPR;
+        if constexpr (extra > 0) {
+            for (int i = threadIdx.x; i < 3 * H * extra; i += SM_THREADS) {
+                const int img = i / extra, rem = i - img * extra;
+                *reinterpret_cast<bf16x8*>(imgs + img * IMG + R * DH + rem * 8) = z;
+            }
         }
         if (threadIdx.x == 0) *reinterpret_cast<bf16x8*>(imgs + 3 * H * IMG) = z;
     }

@@ -304,10 +304,11 @@ __global__ __launch_bounds__(RL_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 // Row 0 of a_{L-1} ... a_1 a_0 per sample, then the class-to-patch part [1:] in one of two final forms:
 // final_mode 0 = as is (trainer.py:44), 1 = divided by its maximum, then softmax (vit_rollout.py:51-55), 2 = divided by
 // its maximum (vit_grad_rollout.py:35).
-// v <- v a_l is split over CH_GROUPS groups of 256 threads (each a slice of the rows, four running sums per
-// thread so the loads stay in flight) and the partial vectors are added in a fixed order.
+// v <- v a_l is split over CH_GROUPS groups of 256 threads (each a slice of the rows, CH_UNROLL running
+// sums per thread so that as many loads are on their way) and the partial vectors are added in a fixed order.
 constexpr int CH_GROUPS = 4;
 constexpr int CH_THREADS = 256 * CH_GROUPS;
+constexpr int CH_UNROLL = 8;         // rows of a layer's matrix a thread has on their way at a time
 __global__ __launch_bounds__(CH_THREADS) void rollout_chain_kernel(const float* __restrict__ a_all, float* __restrict__ out,
                                                                   int L, int B, int N, int final_mode) {
     extern __shared__ float vbuf[];      // v [N], w [N], partial [CH_GROUPS][N]
@@ -324,16 +325,23 @@ __global__ __launch_bounds__(CH_THREADS) void rollout_chain_kernel(const float* 
     for (int l = L - 1; l >= 0; --l) {
         const float* A = a_all + ((long long)l * B + b) * N * N;
         for (int j = t; j < N; j += 256) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            float sacc[CH_UNROLL];
+#pragma unroll
+            for (int u = 0; u < CH_UNROLL; ++u) sacc[u] = 0.f;
             int i = i0;
-            for (; i + 4 <= i1; i += 4) {
-                s0 = fmaf(v[i], A[(long long)i * N + j], s0);
-                s1 = fmaf(v[i + 1], A[(long long)(i + 1) * N + j], s1);
-                s2 = fmaf(v[i + 2], A[(long long)(i + 2) * N + j], s2);
-                s3 = fmaf(v[i + 3], A[(long long)(i + 3) * N + j], s3);
+            for (; i + CH_UNROLL <= i1; i += CH_UNROLL) {
+                float av[CH_UNROLL];
+#pragma unroll
+                for (int u = 0; u < CH_UNROLL; ++u) av[u] = A[(long long)(i + u) * N + j];
+#pragma unroll
+                for (int u = 0; u < CH_UNROLL; ++u) sacc[u] = fmaf(v[i + u], av[u], sacc[u]);
             }
-            for (; i < i1; ++i) s0 = fmaf(v[i], A[(long long)i * N + j], s0);
-            part[g * N + j] = (s0 + s1) + (s2 + s3);
+            for (; i < i1; ++i) sacc[0] = fmaf(v[i], A[(long long)i * N + j], sacc[0]);
+#pragma unroll
+            for (int w2 = CH_UNROLL / 2; w2 > 0; w2 >>= 1)
+#pragma unroll
+                for (int u = 0; u < w2; ++u) sacc[u] += sacc[u + w2];
+            part[g * N + j] = sacc[0];
         }
         __syncthreads();
         for (int j = tid; j < N; j += CH_THREADS) {
