@@ -142,6 +142,33 @@ int vitmi_gemm_wgrad_multi(const vitmi_wgrad_job* jobs, int n, long long T, void
 long long vitmi_ff_block_bwd_du_offset(int dt, int rows, int D, int M);
 long long vitmi_attn_block_bwd_dqkv_offset(int dt, int B, int N, int D, int H, int DH);
 
+/* The vector gradients of many sub-blocks in one launch per 32 jobs (the bias and LayerNorm-parameter gradients of
+ * nn.Linear / nn.LayerNorm's backward, mymodel/ViT.py:55,65-68,88, gathered after the backward pass like the weight
+ * gradients above).  A one-launch sub-block backward leaves per-strip partial sums, `strips` rows of
+ * [db1 (M) | dgamma (D) | dbeta (D) | db2 (D)] fp32; a job sums them over the strips in strip order (the same order and
+ * arithmetic as the reduction the sub-block call runs itself).  M == 0 and db1 == NULL for the attention sub-block
+ * (db2 = the output projection's bias gradient, NULL: none).  jobs is a HOST array.
+ * vitmi_ff_block_bwd / vitmi_attn_block_bwd called with dgamma == NULL (then every other vector-gradient pointer and
+ * both weight-gradient pointers must be NULL too) leave these sums to the caller: the partial sums sit
+ * vitmi_*_block_bwd_sums_offset bytes into that call's workspace, vitmi_*_block_bwd_sums_strips rows of them.  A strips
+ * value of 0 says that the shape does not run as the one-launch kernel: such a call with dgamma == NULL is refused
+ * (VITMI_ERR_BAD_ARG, nothing enqueued), and so is one whose operands miss the 16-byte alignment of that kernel. */
+typedef struct {
+    const float* partial;
+    int strips;
+    int M;
+    int D;
+    float* db1;
+    float* dgamma;
+    float* dbeta;
+    float* db2;
+} vitmi_sums_job;
+int vitmi_small_sums_multi(const vitmi_sums_job* jobs, int n, void* stream);
+long long vitmi_ff_block_bwd_sums_offset(int dt, int rows, int D, int M);
+int vitmi_ff_block_bwd_sums_strips(int dt, int rows, int D, int M);
+long long vitmi_attn_block_bwd_sums_offset(int dt, int B, int N, int D, int H, int DH);
+int vitmi_attn_block_bwd_sums_strips(int dt, int B, int N, int D, int H, int DH);
+
 /* Two weight gradients over the SAME T tokens, C0 [P0,Q0] = U0^T V0 and C1 [P1,Q1] = U1^T V1 (both dense fp32):
  * the two nn.Linear weight gradients of one pre-norm sub-block (mymodel/ViT.py:66,69 resp. :86,89), which autograd
  * computes as two GEMMs.  In bf16 with every extent a multiple of 256 and T a multiple of 64 both run in ONE launch

@@ -364,3 +364,57 @@ def test_deferred_weight_gradients_match_immediate_ones():
     finally:
         ops.set_defer_wgrad(True)
         lib.vitmi_debug_set_small_fused(-1)
+
+
+def test_deferred_vector_sums_match_immediate_ones():
+    """The bias / LayerNorm-parameter gradients of the one-launch sub-block kernels reduced by one
+    vitmi_small_sums_multi launch after the backward pass against the reduction each sub-block call runs itself: the
+    same partial sums through the same arithmetic, so bit for bit; not used when a vector parameter already holds a
+    gradient or carries a hook; a call that asks for it on a shape without the one-launch kernel is refused."""
+    from visiontransformer_amd import ViT, ops
+    from visiontransformer_amd._lib import lib
+    kw = dict(image_size=32, patch_size=4, embed_dim=192, num_classes=10, depth=3, heads=12, mlp_dim=512, dim_head=8)
+    torch.manual_seed(0)
+    m = ViT.VIT(**kw).to(DEV).set_compute_dtype(torch.bfloat16).train()
+    x = torch.randn(32, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (32,), device=DEV)
+
+    def grads(defer_sums, accumulate=False):
+        ops.set_defer_sums(defer_sums)
+        for p in m.parameters():
+            p.grad = torch.zeros_like(p) if accumulate else None
+        before = ops.deferred_stats.get("sums", 0)
+        torch.nn.functional.cross_entropy(m(x), y).backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in m.named_parameters()}, ops.deferred_stats.get("sums", 0) - before
+
+    try:
+        ref, n0 = grads(False)
+        got, n1 = grads(True)
+        assert n0 == 0 and n1 == 2 * kw["depth"]
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+        acc, n2 = grads(True, accumulate=True)          # .grad present: every sub-block forms its own gradients, and
+        assert n2 == 0                                  # through the launch-per-step backward: a bf16-bar comparison
+        for k in ref:
+            assert rel_err(acc[k], ref[k]) < 2e-2, k
+        params = list(m.parameters())
+        for p in params:
+            p.grad = None
+        gs = torch.autograd.grad(torch.nn.functional.cross_entropy(m(x), y), params)
+        torch.cuda.synchronize()
+        for (k, _), g in zip(m.named_parameters(), gs):
+            assert torch.equal(g, ref[k]), k
+        ln = dict(m.named_parameters())["transformer.layers.1.1.norm.weight"]
+        h = ln.register_hook(lambda g: g)               # a tensor hook on one LayerNorm weight: its sub-block does not defer
+        hooked, n3 = grads(True)
+        h.remove()
+        assert n3 == 2 * kw["depth"] - 1
+        for k in ref:
+            assert torch.equal(hooked[k], ref[k]), k
+        # the C entry refuses the request where no one-launch kernel exists (ViT-B/16 widths)
+        assert lib.vitmi_ff_block_bwd_sums_strips(1, 50432, 768, 3072) == 0
+        assert lib.vitmi_attn_block_bwd_sums_strips(1, 256, 197, 768, 12, 64) == 0
+        assert lib.vitmi_attn_block_bwd_sums_strips(1, 32, 65, 192, 12, 8) == 32
+    finally:
+        ops.set_defer_sums(True)

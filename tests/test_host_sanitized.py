@@ -83,6 +83,19 @@ assert lib.vitmi_gemm_wgrad_multi(ctypes.addressof(jobs), 20, 16640, None, None)
 assert lib.vitmi_gemm_wgrad_multi(None, 0, 16640, None, None) == 0
 assert lib.vitmi_ff_block_bwd_du_offset(_lib.BF16, 16640, 192, 512) == 0
 assert lib.vitmi_attn_block_bwd_dqkv_offset(_lib.BF16, 256, 65, 192, 12, 8) == 256 * 65 * 96 * 2
+# the gathered vector sums: where the partial sums sit, how many strips, and the argument checks of the late launch
+assert lib.vitmi_ff_block_bwd_sums_offset(_lib.BF16, 16640, 192, 512) == 16640 * 512 * 2 + 16640 * 192 * 2
+assert lib.vitmi_ff_block_bwd_sums_strips(_lib.BF16, 16640, 192, 512) > 0
+assert lib.vitmi_ff_block_bwd_sums_strips(_lib.BF16, 50432, 768, 3072) == 0
+assert lib.vitmi_ff_block_bwd_sums_strips(_lib.F32, 16640, 192, 512) == 0
+assert lib.vitmi_attn_block_bwd_sums_offset(_lib.BF16, 256, 65, 192, 12, 8) == 256 * 65 * (96 + 288 + 192) * 2
+assert lib.vitmi_attn_block_bwd_sums_strips(_lib.BF16, 256, 65, 192, 12, 8) == 256
+assert lib.vitmi_attn_block_bwd_sums_strips(_lib.BF16, 256, 197, 768, 12, 64) == 0
+assert lib.vitmi_ff_block_bwd_sums_offset(_lib.BF16, big // 4096, 256, 1024) > 0
+from visiontransformer_amd.ops import _SumsJob
+sj = (_SumsJob * 40)()
+assert lib.vitmi_small_sums_multi(None, 0, None) != 0
+assert lib.vitmi_small_sums_multi(ctypes.addressof(sj), 40, None) != 0 and b"job 0" in lib.vitmi_last_error()
 assert lib.vitmi_adam_step_matrices(None, None, 1, 1, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, None) != 0
 # argument checks: a clean error code and a message, never a crash
 assert lib.vitmi_attn_fwd(None, None, None, None, _lib.BF16, 1, 1, 1, 64, 0, None) != 0 and lib.vitmi_last_error()

@@ -123,6 +123,11 @@ SIGNATURES = {
     "vitmi_gemm_wgrad_multi": (I, [P, I, L, P, P]),
     "vitmi_ff_block_bwd_du_offset": (L, [I, I, I, I]),
     "vitmi_attn_block_bwd_dqkv_offset": (L, [I, I, I, I, I, I]),
+    "vitmi_small_sums_multi": (I, [P, I, P]),
+    "vitmi_ff_block_bwd_sums_offset": (L, [I, I, I, I]),
+    "vitmi_ff_block_bwd_sums_strips": (I, [I, I, I, I]),
+    "vitmi_attn_block_bwd_sums_offset": (L, [I, I, I, I, I, I]),
+    "vitmi_attn_block_bwd_sums_strips": (I, [I, I, I, I, I, I]),
 }
 
 

@@ -113,6 +113,7 @@ extern "C" int vitmi_debug_set_wgrad_overlap(int mode) {
 enum { VITMI_SMALL_NOT_TAKEN = 1000 };
 bool vitmi_ff_small_ok(int dt, long long rows, int D, int M);
 bool vitmi_ff_small_bwd_ok(int dt, long long rows, int D, int M, bool caller_forms_dw);
+int vitmi_ff_small_bwd_strips(long long rows, int D, int M);
 long long vitmi_ff_small_bwd_partial_bytes(long long rows, int D, int M);
 int vitmi_ff_small_bwd(long long rows, int D, int M, const void* dy, const void* x, const void* u, const float* gamma,
                        const float* mean, const float* rstd, const void* w2_t, const void* w1_t, void* du, void* dx,
@@ -167,15 +168,31 @@ extern "C" long long vitmi_ff_block_bwd_du_offset(int dt, int rows, int D, int M
     return 0;   // du [rows, M] opens the workspace
 }
 
+extern "C" long long vitmi_ff_block_bwd_sums_offset(int dt, int rows, int D, int M) {
+    if (rows <= 0 || D <= 0 || M <= 0) return 0;
+    return align256((long long)rows * M * esize(dt)) + align256((long long)rows * D * esize(dt));   // behind du and dxn
+}
+extern "C" int vitmi_ff_block_bwd_sums_strips(int dt, int rows, int D, int M) {
+    if (rows <= 0 || D <= 0 || M <= 0 || !vitmi_ff_small_bwd_ok(dt, rows, D, M, true)) return 0;
+    return vitmi_ff_small_bwd_strips(rows, D, M);
+}
+
 extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy, const void* x, const void* xn,
                                   const void* u, const void* h, const float* gamma, const float* mean, const float* rstd,
                                   const void* w1, const void* w1_t, const void* w2, const void* w2_t, void* dx,
                                   float* dgamma, float* dbeta, float* dw1, float* db1, float* dw2, float* db2,
                                   void* workspace, void* stream) {
-    VITMI_CHECK_ARG(dy && x && xn && u && h && gamma && mean && rstd && w1 && w2 && dx && dgamma && dbeta && db1 && db2 &&
-                        workspace && ((dw1 != nullptr) == (dw2 != nullptr)),
+    // dgamma == null: the vector gradients are the caller's as well, later (vitmi_small_sums_multi), from the partial
+    // sums of the one-launch kernel at vitmi_ff_block_bwd_sums_offset in the workspace it keeps until then
+    const bool skip_sums = !dgamma;
+    VITMI_CHECK_ARG(dy && x && xn && u && h && gamma && mean && rstd && w1 && w2 && dx && workspace &&
+                        ((dw1 != nullptr) == (dw2 != nullptr)) &&
+                        (skip_sums ? (!dbeta && !db1 && !db2 && !dw1) : (dbeta && db1 && db2)),
                     "vitmi_ff_block_bwd: null pointer");
     VITMI_CHECK_ARG(rows > 0 && D > 0 && M > 0, "vitmi_ff_block_bwd: bad shape rows=%d D=%d M=%d", rows, D, M);
+    VITMI_CHECK_ARG(!skip_sums || (w1_t && w2_t && vitmi_ff_small_bwd_ok(dt, rows, D, M, true)),
+                    "vitmi_ff_block_bwd: dgamma == NULL (sums left to the caller) needs the one-launch kernel's shape and "
+                    "both transposed weights (vitmi_ff_block_bwd_sums_strips says 0 otherwise)");
     char* ws = (char*)workspace;
     void* du = ws;
     void* dxn = ws + align256((long long)rows * M * esize(dt));
@@ -196,7 +213,9 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
                                           g_classic_gelu_pair, stream);
         if (rc != VITMI_SMALL_NOT_TAKEN) {
             if (rc != VITMI_OK) return rc;
-            if (skip_w) {
+            if (skip_sums) {
+                // nothing: the caller reduces the partial sums
+            } else if (skip_w) {
                 STEP(vitmi_ff_small_bwd_final(rows, D, M, (const float*)scratch, db1, dgamma, dbeta, db2, stream));
             } else if (sd) {
                 STEP(side_fork(sd, stream, true));
@@ -209,6 +228,10 @@ extern "C" int vitmi_ff_block_bwd(int dt, int rows, int D, int M, const void* dy
             }
             return VITMI_OK;
         }
+    }
+    if (skip_sums) {
+        vitmi_set_error("vitmi_ff_block_bwd: dgamma == NULL, but an operand misses the 16-byte alignment of the one-launch kernel");
+        return VITMI_ERR_BAD_ARG;
     }
     STEP(input_grad(dt, rows, M, D, dy, w2, w2_t, du, g_classic_gelu_pair ? VITMI_EPI_DGELU : VITMI_EPI_MULAUX,
                     const_cast<void*>(u), db1, scratch, stream));
@@ -311,16 +334,33 @@ extern "C" long long vitmi_attn_block_bwd_dqkv_offset(int dt, int B, int N, int 
     return align256((long long)B * N * H * DH * esize(dt));   // behind dout [rows, H * DH]
 }
 
+extern "C" long long vitmi_attn_block_bwd_sums_offset(int dt, int B, int N, int D, int H, int DH) {
+    if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || DH <= 0) return 0;
+    const long long rows = (long long)B * N, I = (long long)H * DH;   // behind dout, dqkv and dxn
+    return align256(rows * I * esize(dt)) + align256(rows * 3 * I * esize(dt)) + align256(rows * D * esize(dt));
+}
+extern "C" int vitmi_attn_block_bwd_sums_strips(int dt, int B, int N, int D, int H, int DH) {
+    if (B <= 0 || N <= 0 || D <= 0 || H <= 0 || DH <= 0) return 0;
+    return vitmi_attn_small_bwd_ok(dt, B, N, D, H, DH) ? B : 0;
+}
+
 extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, const void* dy, const void* x,
                                     const void* xn, const void* qkv, const void* o, const float* lse, const float* gamma,
                                     const float* mean, const float* rstd, const void* w_qkv, const void* w_qkv_t,
                                     const void* w_out, const void* w_out_t, void* dx, float* dgamma, float* dbeta,
                                     float* dw_qkv, float* db_qkv, float* dw_out, float* db_out, void* workspace,
                                     int qkv_layout, void* stream) {
-    VITMI_CHECK_ARG(dy && x && xn && qkv && o && lse && gamma && mean && rstd && w_qkv && w_out && dx && dgamma && dbeta &&
-                        workspace && ((dw_qkv != nullptr) == (dw_out != nullptr)),
+    // dgamma == null: the vector gradients are the caller's as well, later (vitmi_small_sums_multi), from the per-image
+    // partial sums of the one-launch kernel at vitmi_attn_block_bwd_sums_offset in the workspace it keeps until then
+    const bool skip_sums = !dgamma;
+    VITMI_CHECK_ARG(dy && x && xn && qkv && o && lse && gamma && mean && rstd && w_qkv && w_out && dx && workspace &&
+                        ((dw_qkv != nullptr) == (dw_out != nullptr)) &&
+                        (skip_sums ? (!dbeta && !db_qkv && !db_out && !dw_qkv) : dbeta != nullptr),
                     "vitmi_attn_block_bwd: null pointer");
     VITMI_CHECK_ARG(B > 0 && N > 0 && D > 0 && H > 0 && DH > 0, "vitmi_attn_block_bwd: bad shape");
+    VITMI_CHECK_ARG(!skip_sums || (!qkv_layout && w_qkv_t && w_out_t && vitmi_attn_small_bwd_ok(dt, B, N, D, H, DH)),
+                    "vitmi_attn_block_bwd: dgamma == NULL (sums left to the caller) needs the one-launch kernel's shape, "
+                    "row-major qkv and both transposed weights (vitmi_attn_block_bwd_sums_strips says 0 otherwise)");
     VITMI_CHECK_ARG(qkv_layout == 0 || qkv_layout == VITMI_QKV_HEAD_MAJOR, "vitmi_attn_block_bwd: bad qkv layout %d", qkv_layout);
     const int rows = B * N, I = H * DH;
     char* ws = (char*)workspace;
@@ -341,8 +381,13 @@ extern "C" int vitmi_attn_block_bwd(int dt, int B, int N, int D, int H, int DH, 
                                             (float*)scratch, stream);
         if (rc != VITMI_SMALL_NOT_TAKEN) {
             if (rc != VITMI_OK) return rc;
+            if (skip_sums) return VITMI_OK;   // the caller reduces the partial sums
             return vitmi_small_sums_final(B, D, (const float*)scratch, dgamma, dbeta, db_out, stream);
         }
+    }
+    if (skip_sums) {
+        vitmi_set_error("vitmi_attn_block_bwd: dgamma == NULL, but an operand misses the 16-byte alignment of the one-launch kernel");
+        return VITMI_ERR_BAD_ARG;
     }
     const bool dq_planes = !skip_w && (g_qkv_planes & 2) && !db_qkv && w_qkv_t &&
                            vitmi_qkv_planes_ok(dt, B, N, D, H, DH, xn, w_qkv_t, dqkv);

@@ -300,14 +300,14 @@ __global__ __launch_bounds__(SM_THREADS) void ff_small_bwd_kernel(FfSmallBwdArgs
 }
 
 // out[c] = sum over the strips' rows of partial[strip][c], in strip order; c runs over [db1 (M) | dgamma | dbeta | db2 (D each)]
-__global__ __launch_bounds__(1024) void ff_small_bwd_final_kernel(const float* __restrict__ partial, int strips, int M, int D,
-                                                                  float* __restrict__ db1, float* __restrict__ dgamma,
-                                                                  float* __restrict__ dbeta, float* __restrict__ db2) {
+__device__ __forceinline__ void sums_final_block(const float* __restrict__ partial, int strips, int M, int D, float* __restrict__ db1,
+                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ db2,
+                                                 int block) {
     // 16 row groups x 64 columns; a group keeps four independent running sums so that its loads overlap (the sums
     // are taken in a fixed order either way)
     const int cols = M + 3 * D;
     const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
+    const int c = block * 64 + lane;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < cols) {
         const float* p = partial + c;
@@ -336,6 +336,21 @@ __global__ __launch_bounds__(1024) void ff_small_bwd_final_kernel(const float* _
         else if (db2)
             db2[c - M - 2 * D] = s;
     }
+}
+__global__ __launch_bounds__(1024) void ff_small_bwd_final_kernel(const float* __restrict__ partial, int strips, int M, int D,
+                                                                  float* __restrict__ db1, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, float* __restrict__ db2) {
+    sums_final_block(partial, strips, M, D, db1, dgamma, dbeta, db2, blockIdx.x);
+}
+// the same for up to SUMS_JOBS sub-blocks: blockIdx.y = job (table by value: capture-safe), blockIdx.x = 64 columns
+constexpr int SUMS_JOBS = 32;
+struct SumsTable {
+    vitmi_sums_job j[SUMS_JOBS];
+};
+__global__ __launch_bounds__(1024) void small_sums_multi_kernel(SumsTable t) {
+    const vitmi_sums_job& j = t.j[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= j.M + 3 * j.D) return;   // whole block: no barrier is skipped by part of one
+    sums_final_block(j.partial, j.strips, j.M, j.D, j.db1, j.dgamma, j.dbeta, j.db2, blockIdx.x);
 }
 
 // token tiles per workgroup: the fewest grid rounds over the CUs, then the smaller strip
@@ -515,5 +530,30 @@ int vitmi_small_sums_final(int strips, int D, const float* partial, float* dgamm
     hipLaunchKernelGGL(ff_small_bwd_final_kernel, dim3((3 * D + 63) / 64), dim3(1024), 0, as_stream(stream), partial, strips, 0, D,
                        nullptr, dgamma, dbeta, db);
     VITMI_LAUNCH_CHECK("ff_small_bwd_final_kernel");
+    return VITMI_OK;
+}
+int vitmi_ff_small_bwd_strips(long long rows, int D, int M) {
+    const int mt = ff_small_bwd_tiles(rows, D, M);
+    return (int)((rows + mt * 16 - 1) / (mt * 16));
+}
+
+extern "C" int vitmi_small_sums_multi(const vitmi_sums_job* jobs, int n, void* stream) {
+    VITMI_CHECK_ARG(jobs && n > 0, "vitmi_small_sums_multi: no jobs");
+    for (int i = 0; i < n; ++i) {
+        const vitmi_sums_job& j = jobs[i];
+        VITMI_CHECK_ARG(j.partial && j.strips > 0 && j.M >= 0 && j.D > 0 && j.dgamma && j.dbeta && (j.M == 0 || j.db1),
+                        "vitmi_small_sums_multi: job %d: bad pointer or shape (strips=%d M=%d D=%d)", i, j.strips, j.M, j.D);
+    }
+    for (int i0 = 0; i0 < n; i0 += SUMS_JOBS) {
+        const int nj = n - i0 < SUMS_JOBS ? n - i0 : SUMS_JOBS;
+        SumsTable t;
+        int cols = 0;
+        for (int i = 0; i < SUMS_JOBS; ++i) {
+            t.j[i] = jobs[i0 + (i < nj ? i : 0)];
+            if (i < nj && t.j[i].M + 3 * t.j[i].D > cols) cols = t.j[i].M + 3 * t.j[i].D;
+        }
+        hipLaunchKernelGGL(small_sums_multi_kernel, dim3((cols + 63) / 64, nj), dim3(1024), 0, as_stream(stream), t);
+        VITMI_LAUNCH_CHECK("small_sums_multi_kernel");
+    }
     return VITMI_OK;
 }

@@ -998,7 +998,15 @@ class _WgradJob(_ct.Structure):
                 ("C", _ct.c_void_p), ("ldc", _ct.c_longlong), ("P", _ct.c_int), ("Q", _ct.c_int)]
 
 
+class _SumsJob(_ct.Structure):
+    _fields_ = [("partial", _ct.c_void_p), ("strips", _ct.c_int), ("M", _ct.c_int), ("D", _ct.c_int),
+                ("db1", _ct.c_void_p), ("dgamma", _ct.c_void_p), ("dbeta", _ct.c_void_p), ("db2", _ct.c_void_p)]
+
+
 _defer_wgrad = os.environ.get("VITMI_DEFER_WGRAD", "1") != "0"
+# the vector gradients (biases, LayerNorm parameters) of the one-launch sub-block kernels ride on the same queue: their
+# per-strip partial sums stay in the kept workspace and one vitmi_small_sums_multi launch reduces all of them
+_defer_sums = os.environ.get("VITMI_DEFER_SUMS", "1") != "0"
 # widths whose weight matrices are a few 128 x 128 tiles each (ViT-S/16 and below): gathered, they fill the chip
 # without token slabs; from ViT-B/16 on the paired 256 x 256 launches of the sub-block calls are the faster form
 _DEFER_MAX_WIDTH = 512
@@ -1012,6 +1020,25 @@ def set_defer_wgrad(on):
     _defer_wgrad = bool(on)
 
 
+def set_defer_sums(on):
+    global _defer_sums
+    _defer_sums = bool(on)
+
+
+def _defer_sums_ok(params):
+    """The gathered vector gradients need what the gathered weight gradients need of their parameters, and fp32
+    parameters: the tensors handed to autograd are the ones the late launch fills."""
+    if not _defer_sums:
+        return False
+    for p in params:
+        if p is None:
+            continue
+        if (p.dtype != torch.float32 or not p.is_leaf or p.grad is not None or p._backward_hooks
+                or getattr(p, "_post_accumulate_grad_hooks", None)):
+            return False
+    return True
+
+
 def _defer_ok(cdt, rows, D, params):
     if not _defer_wgrad or cdt != torch.bfloat16 or D > _DEFER_MAX_WIDTH or _graph_task_id is None:
         return False
@@ -1022,6 +1049,18 @@ def _defer_ok(cdt, rows, D, params):
                 or getattr(p, "_post_accumulate_grad_hooks", None)):
             return False
     return True
+
+
+def _defer_sum_job(device, partial, strips, M, D, outs, params, keep):
+    """outs / params: (db1, dgamma, dbeta, db2) result tensors (None: absent) and the parameters they belong to; the
+    running pass's queue must exist already (the weight jobs of the same call open it)."""
+    st = _deferred[_graph_task_id()]
+    st.setdefault("sums", {}).setdefault((device, _stream()), []).append((partial, strips, M, D,
+                                                                         tuple(None if t is None else _p(t) for t in outs),
+                                                                         tuple(None if t is None else tuple(t.shape) for t in outs),
+                                                                         params))
+    st["keep"].extend(keep)
+    deferred_stats["sums"] = deferred_stats.get("sums", 0) + 1
 
 
 def _defer_jobs(rows, device, jobs, keep):
@@ -1062,6 +1101,23 @@ def _flush_deferred(task):
         with torch.cuda.device(device):
             ws = _ws(lib.vitmi_gemm_wgrad_multi_workspace_bytes(_ct.addressof(arr), len(jobs), rows), device)
             check(lib.vitmi_gemm_wgrad_multi(_ct.addressof(arr), len(jobs), rows, _p(ws), stream), "vitmi_gemm_wgrad_multi")
+    for (device, stream), jobs in st.get("sums", {}).items():
+        arr = (_SumsJob * len(jobs))()
+        for a, (partial, strips, M, D, ptrs, shapes, params) in zip(arr, jobs):
+            ptrs = list(ptrs)
+            for i, prm in enumerate(params):
+                if prm is None or ptrs[i] is None:
+                    continue
+                g = prm.grad
+                if g is not None and g.data_ptr() != ptrs[i]:      # copied, not adopted: fill the copy
+                    if g.dtype != torch.float32 or not g.is_contiguous() or tuple(g.shape) != shapes[i]:
+                        raise RuntimeError("deferred vector gradient: the parameter's .grad is not the fp32 tensor the "
+                                           "backward pass handed to autograd (set_defer_sums(False) for this setup)")
+                    ptrs[i] = g.data_ptr()
+            a.partial, a.strips, a.M, a.D = partial, strips, M, D
+            a.db1, a.dgamma, a.dbeta, a.db2 = ptrs
+        with torch.cuda.device(device):
+            check(lib.vitmi_small_sums_multi(_ct.addressof(arr), len(jobs), stream), "vitmi_small_sums_multi")
 
 
 class _BlockFn(torch.autograd.Function):
@@ -1157,6 +1213,7 @@ class AttnBlockFn(_BlockFn):
         ctx.meta = (B, N, D, heads, dh, add_residual, cdt, ln_w is not None, b_out is not None,
                     ln_w.dtype if ln_w is not None else None, x.dtype)
         ctx.bqkv_dtype = b_qkv.dtype if b_qkv is not None else None
+        ctx.vec_params = (None, ln_w, ln_b, b_out)       # (db1, dgamma, dbeta, db2) slots of the gathered vector sums
         if probs is not None:
             ctx.mark_non_differentiable(probs)
         return y.view(B, N, -1), probs
@@ -1232,16 +1289,25 @@ class AttnBlockFn(_BlockFn):
                 nbytes = _block_ws_bytes[key] = int(lib.vitmi_attn_block_bwd_workspace_bytes(_dt(cdt), B, N, D, heads, dh))
             ws = _ws(nbytes, dev)
             defer = D % 8 == 0 and inner % 8 == 0 and _defer_ok(cdt, rows, D, (w_qkv, w_out))
+            strips = 0
+            if (defer and dbq is None and not ctx.qkv_layout and ln_dtype == f32
+                    and (dbo is None or w_out.dtype == f32) and _defer_sums_ok(ctx.vec_params)):
+                strips = int(lib.vitmi_attn_block_bwd_sums_strips(_dt(cdt), B, N, D, heads, dh))
+            late = strips > 0                # the vector sums ride on the queue as well
             check(lib.vitmi_attn_block_bwd(_dt(cdt), B, N, D, heads, dh, _p(dy2), _p(x2), _p(xn), _p(qkv), _p(o), _p(lse),
                                            _p(g), _p(mean), _p(rstd), _p(compute_copy(w_qkv, cdt)),
                                            _p(weight_t(w_qkv, cdt)), _p(compute_copy(w_out, cdt)),
-                                           _p(weight_t(w_out, cdt)), _p(dx), _p(dg), _p(db),
-                                           None if defer else _p(dwq), _p(dbq), None if defer else _p(dwo),
-                                           _p(dbo), _p(ws), ctx.qkv_layout, _stream()), "vitmi_attn_block_bwd")
+                                           _p(weight_t(w_out, cdt)), _p(dx), None if late else _p(dg),
+                                           None if late else _p(db), None if defer else _p(dwq), _p(dbq),
+                                           None if defer else _p(dwo), None if late else _p(dbo), _p(ws), ctx.qkv_layout,
+                                           _stream()), "vitmi_attn_block_bwd")
             if defer:
                 dqkv = ws.data_ptr() + lib.vitmi_attn_block_bwd_dqkv_offset(_dt(cdt), B, N, D, heads, dh)
                 _defer_jobs(rows, dev, [(_p(dy2), D, _p(o), inner, _p(dwo), D, inner, w_out),
                                         (dqkv, 3 * inner, _p(xn), D, _p(dwq), 3 * inner, D, w_qkv)], (dy2, o, xn, ws))
+            if late:
+                part = ws.data_ptr() + lib.vitmi_attn_block_bwd_sums_offset(_dt(cdt), B, N, D, heads, dh)
+                _defer_sum_job(dev, part, strips, 0, D, (None, dg, db, dbo), ctx.vec_params, (ws,))
             dx = dx.view(B, N, D)
             if dx.dtype != in_dtype:
                 dx = cast(dx, in_dtype)
@@ -1348,6 +1414,7 @@ class FFBlockFn(_BlockFn):
         ctx.aux_epi = EPI_DGELU if (whole and lib.vitmi_get_gelu_mode()) else EPI_MULAUX
         ctx.save_for_backward(x2, g, mean, rstd, xn if ln_w is not None else None, u, h, w1, w2)
         ctx.meta = (shape, add_residual, cdt, ln_w is not None, ln_w.dtype if ln_w is not None else None, x.dtype)
+        ctx.vec_params = (b1, ln_w, ln_b, b2)            # (db1, dgamma, dbeta, db2) slots of the gathered vector sums
         return y.view(*shape[:-1], w2.shape[0])
 
     @staticmethod
@@ -1431,15 +1498,25 @@ class FFBlockFn(_BlockFn):
                 nbytes = _block_ws_bytes[key] = int(lib.vitmi_ff_block_bwd_workspace_bytes(_dt(cdt), rows, D, M))
             ws = _ws(nbytes, dev)
             defer = D % 8 == 0 and M % 8 == 0 and _defer_ok(cdt, rows, D, (w1, w2))
+            strips = 0
+            if (defer and ln_dtype == f32 and w1.dtype == f32 and w2.dtype == f32
+                    and _defer_sums_ok(ctx.vec_params)):
+                strips = int(lib.vitmi_ff_block_bwd_sums_strips(_dt(cdt), rows, D, M))
+            late = strips > 0                # the vector sums ride on the queue as well
             check(lib.vitmi_ff_block_bwd(_dt(cdt), rows, D, M, _p(dy2), _p(x2), _p(xn), _p(u), _p(h), _p(g), _p(mean),
                                          _p(rstd), _p(compute_copy(w1, cdt)), _p(weight_t(w1, cdt)),
-                                         _p(compute_copy(w2, cdt)), _p(weight_t(w2, cdt)), _p(dx), _p(dg), _p(db),
-                                         None if defer else _p(dw1), _p(db1), None if defer else _p(dw2), _p(db2),
+                                         _p(compute_copy(w2, cdt)), _p(weight_t(w2, cdt)), _p(dx),
+                                         None if late else _p(dg), None if late else _p(db),
+                                         None if defer else _p(dw1), None if late else _p(db1),
+                                         None if defer else _p(dw2), None if late else _p(db2),
                                          _p(ws), _stream()), "vitmi_ff_block_bwd")
             if defer:
                 du = ws.data_ptr() + lib.vitmi_ff_block_bwd_du_offset(_dt(cdt), rows, D, M)
                 _defer_jobs(rows, dev, [(_p(dy2), D, _p(h), M, _p(dw2), D, M, w2), (du, M, _p(xn), D, _p(dw1), M, D, w1)],
                             (dy2, h, xn, ws))
+            if late:
+                part = ws.data_ptr() + lib.vitmi_ff_block_bwd_sums_offset(_dt(cdt), rows, D, M)
+                _defer_sum_job(dev, part, strips, M, D, (db1, dg, db, db2), ctx.vec_params, (ws,))
             dx = dx.view(shape)
             if dx.dtype != in_dtype:
                 dx = cast(dx, in_dtype)
