@@ -412,6 +412,24 @@ def test_deferred_vector_sums_match_immediate_ones():
         assert n3 == 2 * kw["depth"] - 1
         for k in ref:
             assert torch.equal(hooked[k], ref[k]), k
+        # more sub-blocks than one launch takes (32): a narrow model of 17 layers
+        kw2 = dict(image_size=32, patch_size=4, embed_dim=64, num_classes=10, depth=17, heads=4, mlp_dim=64, dim_head=16)
+        m2 = ViT.VIT(**kw2).to(DEV).set_compute_dtype(torch.bfloat16).train()
+
+        def grads2(defer_sums):
+            ops.set_defer_sums(defer_sums)
+            for p in m2.parameters():
+                p.grad = None
+            before = ops.deferred_stats.get("sums", 0)
+            torch.nn.functional.cross_entropy(m2(x), y).backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.clone() for k, p in m2.named_parameters()}, ops.deferred_stats.get("sums", 0) - before
+
+        ref2, n4 = grads2(False)
+        got2, n5 = grads2(True)
+        assert n4 == 0 and n5 == 2 * kw2["depth"]
+        for k in ref2:
+            assert torch.equal(got2[k], ref2[k]), k
         # the C entry refuses the request where no one-launch kernel exists (ViT-B/16 widths)
         assert lib.vitmi_ff_block_bwd_sums_strips(1, 50432, 768, 3072) == 0
         assert lib.vitmi_attn_block_bwd_sums_strips(1, 256, 197, 768, 12, 64) == 0
