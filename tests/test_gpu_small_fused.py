@@ -355,6 +355,21 @@ def test_deferred_weight_gradients_match_immediate_ones():
         torch.cuda.synchronize()
         for k, p in m.named_parameters():              # (the checkpointed forward runs the no-grad entry points:
             assert rel_err(p.grad, ref[k]) < 2e-2, k   # the loss gradient differs at the bf16 level)
+        # a pass that wants the input gradient only (torch.autograd.grad(loss, x), as an adversarial-example loop does):
+        # autograd drops the parameter gradients the nodes hand back, so the queue must not write into their memory
+        for p in params:
+            p.grad = None
+        xg = x.clone().requires_grad_(True)
+        dropped0 = ops.deferred_stats.get("dropped", 0)
+        (dx1,) = torch.autograd.grad(torch.nn.functional.cross_entropy(m(xg), y), [xg])
+        torch.cuda.synchronize()
+        n_dropped = ops.deferred_stats.get("dropped", 0) - dropped0
+        assert n_dropped >= 4 * kw["depth"], n_dropped
+        assert all(p.grad is None for p in params)
+        ops.set_defer_wgrad(False)
+        (dx0,) = torch.autograd.grad(torch.nn.functional.cross_entropy(m(xg), y), [xg])
+        ops.set_defer_wgrad(True)
+        assert rel_err(dx1, dx0) < 1e-5
         h = w.register_hook(lambda g: g)                # a tensor hook on one weight: its sub-block does not defer
         hooked, n3 = grads(True)
         h.remove()

@@ -1058,16 +1058,20 @@ def _defer_sum_job(device, partial, strips, M, D, outs, params, keep):
     st.setdefault("sums", {}).setdefault((device, _stream()), []).append((partial, strips, M, D,
                                                                          tuple(None if t is None else _p(t) for t in outs),
                                                                          tuple(None if t is None else tuple(t.shape) for t in outs),
-                                                                         params))
+                                                                         params,
+                                                                         tuple(None if t is None else weakref.ref(t) for t in outs)))
     st["keep"].extend(keep)
     deferred_stats["sums"] = deferred_stats.get("sums", 0) + 1
 
 
 def _defer_jobs(rows, device, jobs, keep):
-    """jobs: (U ptr, ldu, V ptr, ldv, C ptr, P, Q, parameter) over `rows` tokens; keep: tensors the operands live in.
+    """jobs: (U ptr, ldu, V ptr, ldv, C tensor, P, Q, parameter) over `rows` tokens; keep: tensors the operands live in.
     The result tensor itself is NOT kept: a second reference would make autograd's AccumulateGrad copy it (still
-    empty) instead of adopting it as the parameter's .grad.  The queue belongs to the running autograd pass (a pass
-    started from inside another one, as reentrant checkpointing does, has its own)."""
+    empty) instead of adopting it as the parameter's .grad.  Only a weak reference is: a pass that does not want the
+    gradient (torch.autograd.grad / backward(inputs=...) without the parameter) drops the tensor, its memory may serve
+    another tensor by the time the queue is flushed, and the job must then not run.  The queue belongs to the running
+    autograd pass (a pass started from inside another one, as reentrant checkpointing does, has its own)."""
+    jobs = [(U, ldu, V, ldv, _p(C), P, Q, prm, weakref.ref(C)) for (U, ldu, V, ldv, C, P, Q, prm) in jobs]
     task = _graph_task_id()
     st = _deferred.get(task)
     if st is None:
@@ -1087,6 +1091,15 @@ def _flush_deferred(task):
         return
     deferred_stats["flushes"] += 1
     for (device, rows, stream), jobs in st["groups"].items():
+        wanted = []
+        for job in jobs:
+            if job[7].grad is None and job[8]() is None:   # nobody holds the result: the pass did not ask for it
+                deferred_stats["dropped"] = deferred_stats.get("dropped", 0) + 1
+            else:
+                wanted.append(job[:8])
+        jobs = wanted
+        if not jobs:
+            continue
         arr = (_WgradJob * len(jobs))()
         for a, (U, ldu, V, ldv, C, P, Q, param) in zip(arr, jobs):
             g = param.grad
@@ -1103,12 +1116,20 @@ def _flush_deferred(task):
             check(lib.vitmi_gemm_wgrad_multi(_ct.addressof(arr), len(jobs), rows, _p(ws), stream), "vitmi_gemm_wgrad_multi")
     for (device, stream), jobs in st.get("sums", {}).items():
         arr = (_SumsJob * len(jobs))()
-        for a, (partial, strips, M, D, ptrs, shapes, params) in zip(arr, jobs):
+        spare = []
+        for a, (partial, strips, M, D, ptrs, shapes, params, refs) in zip(arr, jobs):
             ptrs = list(ptrs)
             for i, prm in enumerate(params):
                 if prm is None or ptrs[i] is None:
                     continue
                 g = prm.grad
+                if g is None and refs[i]() is None:
+                    # nobody holds this result (the pass did not ask for it) and its memory may be someone else's by
+                    # now: the sum goes to a throw-away tensor
+                    spare.append(torch.empty(shapes[i], dtype=torch.float32, device=device))
+                    ptrs[i] = spare[-1].data_ptr()
+                    deferred_stats["dropped"] = deferred_stats.get("dropped", 0) + 1
+                    continue
                 if g is not None and g.data_ptr() != ptrs[i]:      # copied, not adopted: fill the copy
                     if g.dtype != torch.float32 or not g.is_contiguous() or tuple(g.shape) != shapes[i]:
                         raise RuntimeError("deferred vector gradient: the parameter's .grad is not the fp32 tensor the "
@@ -1303,8 +1324,8 @@ class AttnBlockFn(_BlockFn):
                                            _stream()), "vitmi_attn_block_bwd")
             if defer:
                 dqkv = ws.data_ptr() + lib.vitmi_attn_block_bwd_dqkv_offset(_dt(cdt), B, N, D, heads, dh)
-                _defer_jobs(rows, dev, [(_p(dy2), D, _p(o), inner, _p(dwo), D, inner, w_out),
-                                        (dqkv, 3 * inner, _p(xn), D, _p(dwq), 3 * inner, D, w_qkv)], (dy2, o, xn, ws))
+                _defer_jobs(rows, dev, [(_p(dy2), D, _p(o), inner, dwo, D, inner, w_out),
+                                        (dqkv, 3 * inner, _p(xn), D, dwq, 3 * inner, D, w_qkv)], (dy2, o, xn, ws))
             if late:
                 part = ws.data_ptr() + lib.vitmi_attn_block_bwd_sums_offset(_dt(cdt), B, N, D, heads, dh)
                 _defer_sum_job(dev, part, strips, 0, D, (None, dg, db, dbo), ctx.vec_params, (ws,))
@@ -1512,7 +1533,7 @@ class FFBlockFn(_BlockFn):
                                          _p(ws), _stream()), "vitmi_ff_block_bwd")
             if defer:
                 du = ws.data_ptr() + lib.vitmi_ff_block_bwd_du_offset(_dt(cdt), rows, D, M)
-                _defer_jobs(rows, dev, [(_p(dy2), D, _p(h), M, _p(dw2), D, M, w2), (du, M, _p(xn), D, _p(dw1), M, D, w1)],
+                _defer_jobs(rows, dev, [(_p(dy2), D, _p(h), M, dw2, D, M, w2), (du, M, _p(xn), D, dw1, M, D, w1)],
                             (dy2, h, xn, ws))
             if late:
                 part = ws.data_ptr() + lib.vitmi_ff_block_bwd_sums_offset(_dt(cdt), rows, D, M)
