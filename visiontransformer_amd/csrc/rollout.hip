@@ -49,20 +49,18 @@ struct LayerPtrs {
 };
 
 // hist[bin] += 1 for every lane with `on`.  Fused probabilities share their top bits, so most lanes of a wave hit
-// the same bin: up to two rounds of "the lanes that agree with the first active lane add their count once", then
-// plain LDS atomics for whoever is left.
+// the same bin: the lanes that agree with the first active lane add their count once, the others add on their own.
 __device__ __forceinline__ void hist_add(unsigned int* hist, unsigned bin, bool on) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const unsigned long long act = __ballot(on);
-        if (act == 0ull) return;
-        const int leader = __ffsll((long long)act) - 1;
-        const unsigned lbin = (unsigned)__shfl((int)bin, leader, WAVE);
-        const unsigned long long same = __ballot(on && bin == lbin);
-        if ((int)(threadIdx.x & (WAVE - 1)) == leader) atomicAdd(&hist[lbin], (unsigned)__popcll(same));
-        on = on && bin != lbin;
+    if (on) {
+        const unsigned lbin = (unsigned)__builtin_amdgcn_readfirstlane((int)bin);
+        const unsigned long long same = __ballot(bin == lbin);
+        if (bin == lbin) {
+            if ((int)(threadIdx.x & (WAVE - 1)) == __ffsll((long long)same) - 1)
+                atomicAdd(&hist[lbin], (unsigned)__popcll(same));
+        } else {
+            atomicAdd(&hist[bin], 1u);
+        }
     }
-    if (on) atomicAdd(&hist[bin], 1u);
 }
 
 // a[l][b] = row-normalised ((discard_k(fuse_h probs[l][b,h])) + I) / 2.  One block per (sample, layer).
